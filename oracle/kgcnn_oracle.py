@@ -1,0 +1,835 @@
+"""CPU oracle: a NumPy restatement of the kgcnn ragged scatter-gather hot path.
+
+THIS IS TEST INFRASTRUCTURE, NOT PRODUCT CODE.  Only ``tests/``,
+``__graft_entry__.smoke()`` and the ``cpu_baseline`` leg of ``bench.py`` may import it.
+The product path (``gcnn_keras_amd``) never imports anything from ``oracle/``.
+
+Every function restates, op for op and in float32 unless the inputs are float64, the TF
+op sequence of one reference function and cites it as ``file:line`` relative to the
+reference tree (Tacitus523/gcnn_keras, kgcnn 2.2.3).
+
+Pinning status.  TensorFlow is not installed, so the reference
+path cannot be executed here; the arithmetic of the path lives in the third-party
+dependency ``tensorflow`` (pins: ``>=2.9.0`` setup.py:24, ``==2.12.0`` env_linux.yml:228).
+The oracle is pinned by the reference's own known answers (tests/test_oracle_pins.py):
+
+  1. kgcnn/ops/partition.py:112-120   docstring example of ``partition_row_indexing``
+  2. test/test_gather.py:11-44        ``GatherNodes`` on a 2-graph batch vs NumPy indexing
+  3. test/test_conv_attention.py:34-43 attention pooling known answer ``100/(e+1)``
+  4. test/test_geom.py:79-128 + test/assets/bessel_basis_reference.npz (copied as data to
+     tests/golden/bessel_basis_reference.npz)  NodePosition -> NodeDistanceEuclidean ->
+     BesselBasisLayer(10, 5.0)
+
+Everything else (PoolingLocalEdges sum/mean/max/min values, weighted pooling, PoolingNodes,
+SchNetCFconv / SchNetInteraction, PAiNNconv / PAiNNUpdate, GCN, Gaussian basis, whole-model
+outputs) is **parity unpinned** by the reference's own tests: those results are checked
+against this restatement only, cross-checked by an independent torch-CPU formulation in
+tests/test_oracle_crosscheck.py.
+
+TF semantics relied upon (documented TF behaviour, recalled; TF source is not in the tree):
+sorted ``tf.math.segment_*`` size the output by the last id + 1 and fill missing ids with 0;
+``tf.argsort(stable=True)``; ``tf.scatter_nd`` sums duplicates; ``tf.nn.softplus`` uses the
+thresholded ``log1p(exp(x))`` form; ``divide_no_nan`` returns 0 where the divisor is 0.
+"""
+from collections import namedtuple
+
+import numpy as np
+
+#: Minimal ragged carrier of ragged_rank 1: flat ``values`` plus int64 ``row_splits``.
+R = namedtuple("R", ["values", "row_splits"])
+
+
+def ragged_from_row_lengths(values, row_lengths):
+    row_lengths = np.asarray(row_lengths, dtype=np.int64)
+    splits = np.concatenate([np.zeros(1, dtype=np.int64), np.cumsum(row_lengths, dtype=np.int64)])
+    return R(np.asarray(values), splits)
+
+
+def ragged_from_list(rows, dtype, inner_shape=()):
+    lens = [len(r) for r in rows]
+    if sum(lens) == 0:
+        vals = np.zeros((0,) + tuple(inner_shape), dtype=dtype)
+    else:
+        vals = np.concatenate([np.asarray(r, dtype=dtype).reshape((len(r),) + tuple(inner_shape)) for r in rows], axis=0)
+    return ragged_from_row_lengths(vals, lens)
+
+
+def row_lengths(r):
+    return r.row_splits[1:] - r.row_splits[:-1]
+
+
+def value_rowids(r):
+    lens = row_lengths(r)
+    return np.repeat(np.arange(len(lens), dtype=np.int64), lens)
+
+
+def ragged_rows(r):
+    """List of per-row value arrays (``ragged[i]``)."""
+    return [r.values[r.row_splits[i]:r.row_splits[i + 1]] for i in range(len(r.row_splits) - 1)]
+
+
+# ----------------------------------------------------------------------------------------
+# kgcnn/ops/partition.py
+# ----------------------------------------------------------------------------------------
+
+def change_partition_by_name(in_partition, in_partition_type, out_partition_type):
+    """kgcnn/ops/partition.py:5-93."""
+    p = np.asarray(in_partition)
+    lengths_n = ["row_length", "row_lengths"]
+    splits_n = ["row_split", "row_splits"]
+    starts_n = ["row_start", "row_starts"]
+    limits_n = ["row_limit", "row_limits"]
+
+    def _seg_count(ids):
+        # tf.math.segment_sum(ones_like(ids), ids): rows = last id + 1
+        if len(ids) == 0:
+            return np.zeros(0, dtype=ids.dtype)
+        return np.bincount(ids, minlength=int(ids[-1]) + 1).astype(ids.dtype)
+
+    if in_partition_type == out_partition_type:
+        return p
+    if in_partition_type in lengths_n and out_partition_type in splits_n:
+        return np.pad(np.cumsum(p, dtype=p.dtype), (1, 0))
+    if in_partition_type in lengths_n and out_partition_type == "value_rowids":
+        return np.repeat(np.arange(p.shape[0], dtype=np.int32), p)  # tf.range -> int32 (partition.py:29)
+    if in_partition_type in lengths_n and out_partition_type in starts_n:
+        return np.cumsum(p, dtype=p.dtype) - p
+    if in_partition_type in lengths_n and out_partition_type in limits_n:
+        return np.cumsum(p, dtype=p.dtype)
+    if in_partition_type in splits_n and out_partition_type in lengths_n:
+        return p[1:] - p[:-1]
+    if in_partition_type in splits_n and out_partition_type == "value_rowids":
+        part_sum = p[1:] - p[:-1]
+        return np.repeat(np.arange(part_sum.shape[0], dtype=np.int32), part_sum)
+    if in_partition_type in splits_n and out_partition_type in limits_n:
+        return p[1:]
+    if in_partition_type in splits_n and out_partition_type in starts_n:
+        return p[:-1]
+    if in_partition_type == "value_rowids" and out_partition_type in lengths_n:
+        return _seg_count(p)
+    if in_partition_type == "value_rowids" and out_partition_type in splits_n:
+        return np.pad(np.cumsum(_seg_count(p), dtype=p.dtype), (1, 0))
+    if in_partition_type == "value_rowids" and out_partition_type in limits_n:
+        return np.cumsum(_seg_count(p), dtype=p.dtype)
+    if in_partition_type == "value_rowids" and out_partition_type in starts_n:
+        c = _seg_count(p)
+        return np.cumsum(c, dtype=p.dtype) - c
+    if in_partition_type in starts_n:
+        raise ValueError("Can not infer partition scheme from row_starts alone, missing nvals")
+    if in_partition_type in limits_n and out_partition_type in lengths_n:
+        s = np.pad(p, (1, 0))
+        return s[1:] - s[:-1]
+    if in_partition_type in limits_n and out_partition_type == "value_rowids":
+        s = np.pad(p, (1, 0))
+        part_sum = s[1:] - s[:-1]
+        return np.repeat(np.arange(part_sum.shape[0], dtype=np.int32), part_sum)
+    if in_partition_type in limits_n and out_partition_type in splits_n:
+        return np.pad(p, (1, 0))
+    if in_partition_type in limits_n and out_partition_type in starts_n:
+        return np.pad(p, (1, 0))[:-1]
+    raise TypeError("Unknown partition scheme, use: 'value_rowids', 'row_splits', 'row_lengths', etc.")
+
+
+def partition_row_indexing(tensor_index, part_target, part_index, partition_type_target, partition_type_index,
+                           from_indexing="sample", to_indexing="batch"):
+    """kgcnn/ops/partition.py:97-162: ``idx +/- node_row_splits[graph_of_edge]`` in the index dtype."""
+    tensor_index = np.asarray(tensor_index)
+    if to_indexing == from_indexing:
+        return tensor_index
+    nod_splits = change_partition_by_name(part_target, partition_type_target, "row_splits")
+    edge_ids = change_partition_by_name(part_index, partition_type_index, "value_rowids")
+    shift_index = nod_splits[edge_ids]
+    for _ in range(1, tensor_index.ndim):
+        shift_index = np.expand_dims(shift_index, axis=-1)
+    if to_indexing == "batch" and from_indexing == "sample":
+        return tensor_index + shift_index.astype(tensor_index.dtype)
+    if to_indexing == "sample" and from_indexing == "batch":
+        return tensor_index - shift_index.astype(tensor_index.dtype)
+    raise TypeError("ERROR:kgcnn: Unknown index change, use: 'sample', 'batch', ...")
+
+
+# ----------------------------------------------------------------------------------------
+# kgcnn/ops/segment.py, kgcnn/ops/scatter.py
+# ----------------------------------------------------------------------------------------
+
+def _num_segments(ids):
+    return int(ids[-1]) + 1 if len(ids) > 0 else 0
+
+
+def segment_sum(data, ids):
+    """``tf.math.segment_sum`` for sorted ids: rows = last id + 1, gaps 0, sequential accumulation
+    in row order (``np.add.at`` is unbuffered and applies the updates in index order)."""
+    data = np.asarray(data)
+    out = np.zeros((_num_segments(ids),) + data.shape[1:], dtype=data.dtype)
+    np.add.at(out, np.asarray(ids, dtype=np.int64), data)
+    return out
+
+
+def segment_mean(data, ids):
+    data = np.asarray(data)
+    n = _num_segments(ids)
+    s = segment_sum(data, ids)
+    cnt = np.bincount(np.asarray(ids, dtype=np.int64), minlength=n).astype(data.dtype)
+    cnt = cnt.reshape((n,) + (1,) * (data.ndim - 1))
+    with np.errstate(divide="ignore", invalid="ignore"):
+        out = s / cnt
+    return np.where(cnt > 0, out, np.zeros_like(out)).astype(data.dtype)
+
+
+def _segment_extreme(data, ids, ufunc, init):
+    data = np.asarray(data)
+    n = _num_segments(ids)
+    ids = np.asarray(ids, dtype=np.int64)
+    out = np.full((n,) + data.shape[1:], init, dtype=data.dtype)
+    ufunc.at(out, ids, data)
+    present = np.bincount(ids, minlength=n) > 0
+    out[~present] = 0
+    return out
+
+
+def segment_max(data, ids):
+    return _segment_extreme(data, ids, np.maximum, -np.inf)
+
+
+def segment_min(data, ids):
+    return _segment_extreme(data, ids, np.minimum, np.inf)
+
+
+def segment_ops_by_name(segment_name, data, segment_ids):
+    """kgcnn/ops/segment.py:28-52."""
+    if segment_name in ["segment_mean", "mean", "reduce_mean"]:
+        return segment_mean(data, segment_ids)
+    if segment_name in ["segment_sum", "sum", "reduce_sum"]:
+        return segment_sum(data, segment_ids)
+    if segment_name in ["segment_max", "max", "reduce_max"]:
+        return segment_max(data, segment_ids)
+    if segment_name in ["segment_min", "min", "reduce_min"]:
+        return segment_min(data, segment_ids)
+    raise TypeError("Unknown segment operation, choose: 'segment_mean', 'segment_sum', ...")
+
+
+def segment_softmax(data, segment_ids, normalize=True):
+    """kgcnn/ops/segment.py:5-24."""
+    data = np.asarray(data)
+    if normalize:
+        data_segment_max = segment_max(data, segment_ids)
+        data = data - data_segment_max[segment_ids]
+    data_exp = np.exp(data)
+    data_exp_segment_sum = segment_sum(data_exp, segment_ids)
+    return data_exp / data_exp_segment_sum[segment_ids]
+
+
+def tensor_scatter_nd_ops_by_name(segment_name, tensor, indices, updates):
+    """kgcnn/ops/scatter.py:5-26 (``tf.tensor_scatter_nd_{add,max,min}``)."""
+    out = np.array(tensor, copy=True)
+    idx = tuple(np.asarray(indices)[:, k] for k in range(np.asarray(indices).shape[1]))
+    if segment_name in ["segment_sum", "sum", "reduce_sum", "add"]:
+        np.add.at(out, idx, updates)
+    elif segment_name in ["segment_max", "max", "reduce_max"]:
+        np.maximum.at(out, idx, updates)
+    elif segment_name in ["segment_min", "min", "reduce_min"]:
+        np.minimum.at(out, idx, updates)
+    else:
+        raise TypeError("Unknown pooling, choose: 'mean', 'sum', ...")
+    return out
+
+
+# ----------------------------------------------------------------------------------------
+# Activations: kgcnn/ops/activ.py:6-15 and the Keras strings used by SchNet / PaiNN / GCN
+# ----------------------------------------------------------------------------------------
+
+def softplus(x):
+    """``tf.nn.softplus``: x if x > -thr ; exp(x) if x < thr ; else log1p(exp(x)),
+    thr = log(eps) + 2 (TF ``softplus_op.h`` functor, recalled)."""
+    x = np.asarray(x)
+    thr = np.log(np.finfo(x.dtype).eps).astype(x.dtype) + x.dtype.type(2)
+    with np.errstate(over="ignore"):
+        ex = np.exp(x)
+        mid = np.log1p(ex)
+    return np.where(x > -thr, x, np.where(x < thr, ex, mid)).astype(x.dtype)
+
+
+def shifted_softplus(x):
+    """kgcnn/ops/activ.py:15: ``softplus(x) - log(2.0)`` in the input dtype."""
+    x = np.asarray(x)
+    return (softplus(x) - np.log(x.dtype.type(2.0))).astype(x.dtype)
+
+
+def sigmoid(x):
+    x = np.asarray(x)
+    with np.errstate(over="ignore"):
+        return (x.dtype.type(1) / (x.dtype.type(1) + np.exp(-x))).astype(x.dtype)
+
+
+def swish(x):
+    x = np.asarray(x)
+    return (x * sigmoid(x)).astype(x.dtype)
+
+
+def softmax_last(x):
+    x = np.asarray(x)
+    e = np.exp(x - np.max(x, axis=-1, keepdims=True))
+    return (e / np.sum(e, axis=-1, keepdims=True)).astype(x.dtype)
+
+
+def leaky_relu(x, alpha=0.05):
+    """kgcnn/ops/activ.py:59-80 ``kgcnn>leaky_relu`` (default alpha 0.05)."""
+    x = np.asarray(x)
+    return np.where(x >= 0, x, x.dtype.type(alpha) * x).astype(x.dtype)
+
+
+ACTIVATIONS = {
+    None: lambda x: x,
+    "linear": lambda x: x,
+    "relu": lambda x: np.maximum(x, 0).astype(np.asarray(x).dtype),
+    "kgcnn>shifted_softplus": shifted_softplus,
+    "shifted_softplus": shifted_softplus,
+    "softplus": softplus,
+    "swish": swish,
+    "sigmoid": sigmoid,
+    "tanh": np.tanh,
+    "softmax": softmax_last,
+    "kgcnn>leaky_relu": leaky_relu,
+}
+
+
+def activation(name, x):
+    if callable(name):
+        return name(x)
+    return ACTIVATIONS[name](x)
+
+
+# ----------------------------------------------------------------------------------------
+# kgcnn/layers/modules.py, kgcnn/layers/mlp.py
+# ----------------------------------------------------------------------------------------
+
+def dense_values(x, kernel, bias=None, act=None):
+    """Keras ``Dense`` on the last axis of a values tensor (kgcnn/layers/modules.py:74-87):
+    ``act(x @ kernel + bias)``, kernel layout ``(in, units)``."""
+    x = np.asarray(x)
+    y = np.matmul(x, kernel.astype(x.dtype))
+    if bias is not None:
+        y = y + bias.astype(x.dtype)
+    return activation(act, y)
+
+
+def dense(r, kernel, bias=None, act=None):
+    if isinstance(r, R):
+        return R(dense_values(r.values, kernel, bias, act), r.row_splits)
+    return dense_values(r, kernel, bias, act)
+
+
+def mlp(r, layers):
+    """kgcnn/layers/mlp.py:299-316 with dropout / normalisation off: Dense(linear) then Activation.
+    ``layers``: list of ``(kernel, bias_or_None, activation_name)``."""
+    x = r
+    for kernel, bias, act in layers:
+        x = dense(x, kernel, bias, None)
+        if isinstance(x, R):
+            x = R(activation(act, x.values), x.row_splits)
+        else:
+            x = activation(act, x)
+    return x
+
+
+def embedding(r, table):
+    """Keras ``Embedding`` on ragged float node numbers (kgcnn/layers/modules.py:526-528;
+    kgcnn/literature/Schnet.py:26 declares float32): the input is cast to int32, then looked up."""
+    idx = np.asarray(r.values).astype(np.int32)
+    return R(table[idx], r.row_splits)
+
+
+def lazy_add(rs):
+    out = rs[0].values
+    for x in rs[1:]:
+        out = out + x.values
+    return R(out, rs[0].row_splits)
+
+
+def lazy_subtract(rs):
+    return R(rs[0].values - rs[1].values, rs[0].row_splits)
+
+
+def lazy_multiply(rs):
+    out = rs[0].values
+    for x in rs[1:]:
+        out = out * x.values
+    return R(out, rs[0].row_splits)
+
+
+def lazy_concatenate(rs, axis=-1):
+    """kgcnn/layers/modules.py:305-364 on values; ragged axis>1 maps to values axis-1 (base.py:131-144)."""
+    nd = rs[0].values.ndim + 1
+    ax = axis if axis >= 0 else axis + nd
+    return R(np.concatenate([x.values for x in rs], axis=ax - 1), rs[0].row_splits)
+
+
+def expand_dims(r, axis=-1):
+    """kgcnn/layers/modules.py:368-416 (axis normalised against rank+1 of the ragged tensor)."""
+    nd = r.values.ndim + 1
+    ax = axis if axis >= 0 else axis + nd + 1
+    return R(np.expand_dims(r.values, axis=ax - 1), r.row_splits)
+
+
+# ----------------------------------------------------------------------------------------
+# kgcnn/layers/gather.py
+# ----------------------------------------------------------------------------------------
+
+def _shift(nodes, idx):
+    return partition_row_indexing(idx.values, nodes.row_splits, row_lengths(idx),
+                                  partition_type_target="row_splits", partition_type_index="row_length",
+                                  to_indexing="batch", from_indexing="sample")
+
+
+def gather_nodes(nodes, idx, concat_axis=2, split_axis=None):
+    """``GatherEmbedding`` fast path, kgcnn/layers/gather.py:69-99.  Default output ``[x_i || x_j]``."""
+    if split_axis is not None and concat_axis is not None:
+        raise ValueError("Can not both split and concatenate new index axis. At least one must be `None`.")
+    disjoint = _shift(nodes, idx)
+    out = nodes.values[disjoint]  # (M, K, F...)
+    if concat_axis == 2:
+        out = np.concatenate([out[:, i] for i in range(idx.values.shape[1])], axis=1)
+        return R(out, idx.row_splits)
+    if split_axis == 2:
+        return [R(out[:, i], idx.row_splits) for i in range(idx.values.shape[1])]
+    return R(out, idx.row_splits)
+
+
+def gather_nodes_selection(nodes, idx, selection_index):
+    """``GatherEmbeddingSelection``, kgcnn/layers/gather.py:217-231: always returns a list."""
+    if isinstance(selection_index, int):
+        selection_index = [selection_index]
+    indexlist = _shift(nodes, idx)
+    return [R(nodes.values[indexlist[:, i]], idx.row_splits) for i in selection_index]
+
+
+def gather_nodes_ingoing(nodes, idx):
+    """kgcnn/layers/gather.py:249-282 (selection_index 0 = receiver i)."""
+    return gather_nodes_selection(nodes, idx, 0)[0]
+
+
+def gather_nodes_outgoing(nodes, idx):
+    """kgcnn/layers/gather.py:286-319 (selection_index 1 = sender j)."""
+    return gather_nodes_selection(nodes, idx, 1)[0]
+
+
+def gather_state(state, target):
+    """kgcnn/layers/gather.py:323-375: ``tf.repeat(state, target.row_lengths(), axis=0)``."""
+    lens = row_lengths(target)
+    return R(np.repeat(np.asarray(state), lens, axis=0), target.row_splits)
+
+
+# ----------------------------------------------------------------------------------------
+# kgcnn/layers/pooling.py
+# ----------------------------------------------------------------------------------------
+
+def _scatter_pad(out, n_rows):
+    """``tf.scatter_nd(range(rows)[:, None], out, (N, ...))`` (pooling.py:74-76): zero-pad tail rows."""
+    padded = np.zeros((n_rows,) + out.shape[1:], dtype=out.dtype)
+    padded[:out.shape[0]] = out
+    return padded
+
+
+def pooling_local_edges(nodes, edges, idx, pooling_method="mean", pooling_index=0,
+                        is_sorted=False, has_unconnected=True):
+    """``PoolingLocalEdges.call``, kgcnn/layers/pooling.py:37-79."""
+    shiftind = _shift(nodes, idx)
+    nodind = shiftind[:, pooling_index]
+    dens = edges.values
+    if not is_sorted:
+        node_order = np.argsort(nodind, axis=0, kind="stable")
+        nodind = nodind[node_order]
+        dens = dens[node_order]
+    out = segment_ops_by_name(pooling_method, dens, nodind)
+    if has_unconnected:
+        out = _scatter_pad(out, nodes.values.shape[0])
+    return R(out, nodes.row_splits)
+
+
+def pooling_weighted_local_edges(nodes, edges, idx, weights, pooling_method="mean", normalize_by_weights=False,
+                                 pooling_index=0, is_sorted=False, has_unconnected=True):
+    """``PoolingWeightedLocalEdges.call``, kgcnn/layers/pooling.py:126-176."""
+    shiftind = _shift(nodes, idx)
+    wval = weights.values
+    dens = edges.values * wval
+    nodind = shiftind[:, pooling_index]
+    if not is_sorted:
+        node_order = np.argsort(nodind, axis=0, kind="stable")
+        nodind = nodind[node_order]
+        dens = dens[node_order]
+        wval = wval[node_order]
+    get = segment_ops_by_name(pooling_method, dens, nodind)
+    if normalize_by_weights:
+        den = segment_sum(wval, nodind)
+        with np.errstate(divide="ignore", invalid="ignore"):
+            q = get / den
+        get = np.where(den == 0, np.zeros_like(q), q).astype(get.dtype)
+    if has_unconnected:
+        get = _scatter_pad(get, nodes.values.shape[0])
+    return R(get, nodes.row_splits)
+
+
+def pooling_nodes(nodes, pooling_method="mean"):
+    """``PoolingEmbedding.call``, kgcnn/layers/pooling.py:203-219: dense ``(max(rowid)+1, F)``."""
+    return segment_ops_by_name(pooling_method, nodes.values, value_rowids(nodes))
+
+
+def pooling_weighted_nodes(nodes, weights, pooling_method="mean"):
+    """``PoolingWeightedEmbedding.call``, kgcnn/layers/pooling.py:257-276."""
+    return segment_ops_by_name(pooling_method, nodes.values * weights.values, value_rowids(nodes))
+
+
+def pooling_local_edges_attention(nodes, edges, attention, idx, pooling_index=0, is_sorted=False,
+                                  has_unconnected=True):
+    """``PoolingLocalEdgesAttention.call``, kgcnn/layers/pooling.py:494-541."""
+    shiftind = _shift(nodes, idx)
+    nodind = shiftind[:, pooling_index]
+    dens = edges.values
+    ats = attention.values
+    if not is_sorted:
+        node_order = np.argsort(nodind, axis=0, kind="stable")
+        nodind = nodind[node_order]
+        dens = dens[node_order]
+        ats = ats[node_order]
+    ats = segment_softmax(ats, nodind)
+    get = segment_sum(dens * ats, nodind)
+    if has_unconnected:
+        get = _scatter_pad(get, nodes.values.shape[0])
+    return R(get, nodes.row_splits)
+
+
+def pooling_nodes_attention(nodes, attention):
+    """``PoolingEmbeddingAttention.call``, kgcnn/layers/pooling.py:570-591."""
+    batchi = value_rowids(nodes)
+    ats = segment_softmax(attention.values, batchi)
+    return segment_sum(nodes.values * ats, batchi)
+
+
+def relational_pooling_local_edges(nodes, edges, idx, edge_relation, num_relations, pooling_method="sum",
+                                   pooling_index=0):
+    """``RelationalPoolingLocalEdges.call``, kgcnn/layers/pooling.py:630-668."""
+    shiftind = _shift(nodes, idx)
+    indices = shiftind[:, pooling_index]
+    relations = edge_relation.values.astype(indices.dtype)
+    scatter_indices = np.stack([indices, relations], axis=-1)
+    out_tensor = np.zeros((nodes.values.shape[0], num_relations) + edges.values.shape[1:], dtype=edges.values.dtype)
+    out = tensor_scatter_nd_ops_by_name(pooling_method, out_tensor, scatter_indices, edges.values)
+    return R(out, nodes.row_splits)
+
+
+# ----------------------------------------------------------------------------------------
+# kgcnn/layers/geom.py
+# ----------------------------------------------------------------------------------------
+
+def node_position(xyz, idx, selection_index=(0, 1)):
+    """``NodePosition``, kgcnn/layers/geom.py:14-73 = ``GatherNodesSelection([0, 1])``."""
+    return gather_nodes_selection(xyz, idx, list(selection_index))
+
+
+def euclidean_norm_values(x, axis=-1, keepdims=False, invert_norm=False, add_eps=False, no_nan=True,
+                          square_norm=False, epsilon=1e-7):
+    """``EuclideanNorm._compute_euclidean_norm``, kgcnn/layers/geom.py:166-193: ``sqrt(relu(sum(x^2)))``.
+    ``epsilon`` = ``ks.backend.epsilon()`` default 1e-7."""
+    x = np.asarray(x)
+    out = np.maximum(np.sum(np.square(x), axis=axis, keepdims=keepdims), 0).astype(x.dtype)
+    if add_eps:
+        out = out + x.dtype.type(epsilon)
+    if not square_norm:
+        out = np.sqrt(out)
+    if invert_norm:
+        with np.errstate(divide="ignore", invalid="ignore"):
+            inv = x.dtype.type(1) / out
+        if no_nan:
+            inv = np.where(out == 0, np.zeros_like(inv), inv)
+        out = inv.astype(x.dtype)
+    return out
+
+
+def euclidean_norm(r, axis=-1, **kw):
+    """Ragged wrapper: ``axis`` refers to the ragged tensor (batch axis 0), mapped to values axis-1."""
+    nd = r.values.ndim + 1
+    ax = axis if axis >= 0 else axis + nd
+    return R(euclidean_norm_values(r.values, axis=ax - 1, **kw), r.row_splits)
+
+
+def scalar_product(a, b, axis=-1):
+    """``ScalarProduct``, kgcnn/layers/geom.py:250-261."""
+    nd = a.values.ndim + 1
+    ax = axis if axis >= 0 else axis + nd
+    return R(np.sum(a.values * b.values, axis=ax - 1), a.row_splits)
+
+
+def node_distance_euclidean(pos1, pos2, add_eps=False, no_nan=True):
+    """``NodeDistanceEuclidean``, kgcnn/layers/geom.py:285-327: ``||x_1 - x_2||`` with keepdims."""
+    diff = lazy_subtract([pos1, pos2])
+    return euclidean_norm(diff, axis=2, keepdims=True, add_eps=add_eps, no_nan=no_nan)
+
+
+def edge_direction_normalized(pos1, pos2, add_eps=False, no_nan=True):
+    """``EdgeDirectionNormalized``, kgcnn/layers/geom.py:331-378: ``d * divide_no_nan(1, ||d||)``."""
+    diff = lazy_subtract([pos1, pos2])
+    norm = euclidean_norm(diff, axis=2, keepdims=True, invert_norm=True, add_eps=add_eps, no_nan=no_nan)
+    return lazy_multiply([diff, norm])
+
+
+def gauss_basis(d, bins=20, distance=4.0, sigma=0.4, offset=0.0):
+    """``GaussBasisLayer._compute_gauss_basis``, kgcnn/layers/geom.py:554-571."""
+    x = np.asarray(d.values)
+    dt = x.dtype
+    gamma = 1 / sigma / sigma / 2  # geom.py:549 (python float)
+    gbs = np.arange(0, int(bins), 1, dtype=dt) / dt.type(float(bins)) * dt.type(distance)
+    out = x - dt.type(offset)
+    out = np.square(out - gbs) * dt.type(gamma * (-1.0))
+    return R(np.exp(out).astype(dt), d.row_splits)
+
+
+def bessel_basis(d, num_radial, cutoff, envelope_exponent=5, frequencies=None):
+    """``BesselBasisLayer.expand_bessel_basis`` + ``envelope``, kgcnn/layers/geom.py:772-785.
+    ``frequencies`` default ``pi * arange(1, num_radial + 1)`` float32 (geom.py:766-770)."""
+    x = np.asarray(d.values)
+    dt = x.dtype
+    if frequencies is None:
+        frequencies = (np.pi * np.arange(1, num_radial + 1, dtype=np.float32))
+    frequencies = np.asarray(frequencies).astype(dt)
+    inv_cutoff = dt.type(np.float32(1 / cutoff))
+    d_scaled = x * inv_cutoff
+    p = envelope_exponent + 1
+    a = -(p + 1) * (p + 2) / 2
+    b = p * (p + 2)
+    c = -p * (p + 1) / 2
+    with np.errstate(divide="ignore", invalid="ignore"):
+        env_val = (dt.type(1.0) / d_scaled + dt.type(a) * d_scaled ** (p - 1) + dt.type(b) * d_scaled ** p
+                   + dt.type(c) * d_scaled ** (p + 1))
+    d_cutoff = np.where(d_scaled < 1, env_val, np.zeros_like(d_scaled))
+    out = d_cutoff * np.sin(frequencies * d_scaled)
+    return R(out.astype(dt), d.row_splits)
+
+
+def cos_cutoff_envelope(d, cutoff):
+    """``CosCutOffEnvelope``, kgcnn/layers/geom.py:829-837 (``cutoff=None`` -> 1e8)."""
+    x = np.asarray(d.values)
+    dt = x.dtype
+    cutoff = float(np.abs(cutoff)) if cutoff is not None else 1e8
+    fc = np.clip(x, dt.type(-cutoff), dt.type(cutoff))
+    fc = (np.cos(fc * dt.type(np.pi) / dt.type(cutoff)) + dt.type(1)) * dt.type(0.5)
+    return R(fc.astype(dt), d.row_splits)
+
+
+# ----------------------------------------------------------------------------------------
+# kgcnn/layers/conv/schnet_conv.py, kgcnn/literature/Schnet.py
+# ----------------------------------------------------------------------------------------
+
+def schnet_cfconv(node, edge, idx, p, act="kgcnn>shifted_softplus", cfconv_pool="sum"):
+    """``SchNetCFconv.call``, kgcnn/layers/conv/schnet_conv.py:73-79.
+    ``p``: dict with dense1/dense2 kernel + bias."""
+    x = dense(edge, p["dense1/kernel"], p.get("dense1/bias"), act)
+    x = dense(x, p["dense2/kernel"], p.get("dense2/bias"), "linear")
+    node2exp = gather_nodes_outgoing(node, idx)
+    x = lazy_multiply([node2exp, x])
+    return pooling_local_edges(node, x, idx, pooling_method=cfconv_pool)
+
+
+def schnet_interaction(node, edge, idx, p, act="kgcnn>shifted_softplus", cfconv_pool="sum"):
+    """``SchNetInteraction.call``, kgcnn/layers/conv/schnet_conv.py:159-165."""
+    x = dense(node, p["dense1/kernel"], None, "linear")
+    x = schnet_cfconv(x, edge, idx, {k[len("cfconv/"):]: v for k, v in p.items() if k.startswith("cfconv/")},
+                      act=act, cfconv_pool=cfconv_pool)
+    x = dense(x, p["dense2/kernel"], p.get("dense2/bias"), act)
+    x = dense(x, p["dense3/kernel"], p.get("dense3/bias"), "linear")
+    return lazy_add([node, x])
+
+
+def _sub(params, prefix):
+    return {k[len(prefix):]: v for k, v in params.items() if k.startswith(prefix)}
+
+
+def schnet_forward(params, node_number, xyz, idx, depth=3, gauss_args=None, act="kgcnn>shifted_softplus",
+                   cfconv_pool="sum", node_pooling="sum",
+                   last_mlp_act=("kgcnn>shifted_softplus", "kgcnn>shifted_softplus"),
+                   output_mlp_act=("kgcnn>shifted_softplus", "linear"), return_intermediate=False):
+    """``kgcnn.literature.Schnet.make_model`` forward, kgcnn/literature/Schnet.py:104-148
+    (graph output, ``make_distance=True, expand_distance=True``)."""
+    gauss_args = gauss_args or {"bins": 20, "distance": 4, "offset": 0.0, "sigma": 0.4}
+    inter = {}
+    n = embedding(node_number, params["embedding"])
+    pos1, pos2 = node_position(xyz, idx)
+    ed = node_distance_euclidean(pos1, pos2)
+    inter["distance"] = ed.values
+    ed = gauss_basis(ed, **gauss_args)
+    inter["rbf"] = ed.values
+    n = dense(n, params["dense0/kernel"], params["dense0/bias"], "linear")
+    for i in range(depth):
+        n = schnet_interaction(n, ed, idx, _sub(params, "interaction%d/" % i), act=act, cfconv_pool=cfconv_pool)
+        inter["n%d" % i] = n.values
+    n = mlp(n, [(params["last_mlp/%d/kernel" % k], params.get("last_mlp/%d/bias" % k), last_mlp_act[k])
+                for k in range(len(last_mlp_act))])
+    inter["last_mlp"] = n.values
+    out = pooling_nodes(n, node_pooling)
+    inter["pooled"] = out
+    out = mlp(out, [(params["output_mlp/%d/kernel" % k], params.get("output_mlp/%d/bias" % k), output_mlp_act[k])
+                    for k in range(len(output_mlp_act))])
+    if return_intermediate:
+        return out, inter
+    return out
+
+
+# ----------------------------------------------------------------------------------------
+# kgcnn/layers/conv/painn_conv.py, kgcnn/literature/PAiNN.py
+# ----------------------------------------------------------------------------------------
+
+def equivariant_initialize(z, dim=3, method="zeros", value=1.0, epsilon=1e-7):
+    """``EquivariantInitialize.call``, kgcnn/layers/conv/painn_conv.py:261-290 (zeros/eps/ones/const/node)."""
+    v = z.values
+    if method == "zeros":
+        out = np.zeros_like(v)
+    elif method == "eps":
+        out = np.zeros_like(v) + v.dtype.type(epsilon)
+    elif method == "ones":
+        out = np.ones_like(v)
+    elif method == "const":
+        out = np.ones_like(v) * v.dtype.type(value)
+    elif method == "node":
+        out = v
+    else:
+        raise ValueError("Unknown initialization method %s" % method)
+    out = np.repeat(np.expand_dims(out, axis=1), dim, axis=1)
+    return R(out, z.row_splits)
+
+
+def split_embedding(r, num):
+    """``SplitEmbedding``, kgcnn/layers/conv/painn_conv.py:329-340 (equal split of the last axis)."""
+    return [R(x, r.row_splits) for x in np.split(r.values, num, axis=-1)]
+
+
+def painn_conv(node, equivariant, rbf, envelope, r_ij, idx, p, act="swish", cutoff=None, conv_pool="sum"):
+    """``PAiNNconv.call``, kgcnn/layers/conv/painn_conv.py:97-115."""
+    s = dense(node, p["dense1/kernel"], p.get("dense1/bias"), act)
+    s = dense(s, p["phi/kernel"], p.get("phi/bias"), "linear")
+    s = gather_nodes_outgoing(s, idx)
+    w = dense(rbf, p["w/kernel"], p.get("w/bias"), "linear")
+    if cutoff is not None:
+        w = lazy_multiply([w, envelope])
+    sw = lazy_multiply([s, w])
+    sw1, sw2, sw3 = split_embedding(sw, 3)
+    ds = pooling_local_edges(node, sw1, idx, pooling_method=conv_pool)
+    vj = gather_nodes_outgoing(equivariant, idx)
+    sw2 = expand_dims(sw2, axis=-2)
+    dv1 = lazy_multiply([sw2, vj])
+    sw3 = expand_dims(sw3, axis=-2)
+    r_ij = expand_dims(r_ij, axis=-1)
+    dv2 = lazy_multiply([sw3, r_ij])
+    dv = lazy_add([dv1, dv2])
+    dv = pooling_local_edges(node, dv, idx, pooling_method=conv_pool)
+    return ds, dv
+
+
+def painn_update(node, equivariant, p, act="swish"):
+    """``PAiNNUpdate.call``, kgcnn/layers/conv/painn_conv.py:201-214."""
+    v_v = dense(equivariant, p["lin_v/kernel"], None, "linear")
+    v_u = dense(equivariant, p["lin_u/kernel"], None, "linear")
+    v_prod = scalar_product(v_u, v_v, axis=2)
+    v_norm = euclidean_norm(v_v, axis=2)
+    a = lazy_concatenate([node, v_norm], axis=-1)
+    a = dense(a, p["dense1/kernel"], p.get("dense1/bias"), act)
+    a = dense(a, p["a/kernel"], p.get("a/bias"), "linear")
+    a_vv, a_sv, a_ss = split_embedding(a, 3)
+    a_vv = expand_dims(a_vv, axis=-2)
+    dv = lazy_multiply([a_vv, v_u])
+    ds = lazy_multiply([v_prod, a_sv])
+    ds = lazy_add([ds, a_ss])
+    return ds, dv
+
+
+def painn_forward(params, node_number, xyz, idx, depth=3, bessel_args=None, cutoff=None, equiv_method="zeros",
+                  act="swish", conv_pool="sum", node_pooling="sum", output_mlp_act=("swish", "linear"),
+                  return_intermediate=False):
+    """``kgcnn.literature.PAiNN.make_model`` forward, kgcnn/literature/PAiNN.py:100-155 (graph output)."""
+    bessel_args = bessel_args or {"num_radial": 20, "cutoff": 5.0, "envelope_exponent": 5}
+    inter = {}
+    z = embedding(node_number, params["embedding"])
+    v = equivariant_initialize(z, dim=3, method=equiv_method)
+    pos1, pos2 = node_position(xyz, idx)
+    rij = edge_direction_normalized(pos1, pos2)
+    d = node_distance_euclidean(pos1, pos2)
+    env = cos_cutoff_envelope(d, cutoff)
+    rbf = bessel_basis(d, frequencies=params.get("bessel/frequencies"), **bessel_args)
+    inter["rbf"] = rbf.values
+    inter["rij"] = rij.values
+    for i in range(depth):
+        ds, dv = painn_conv(z, v, rbf, env, rij, idx, _sub(params, "conv%d/" % i), act=act, cutoff=cutoff,
+                            conv_pool=conv_pool)
+        z = lazy_add([z, ds])
+        v = lazy_add([v, dv])
+        ds, dv = painn_update(z, v, _sub(params, "update%d/" % i), act=act)
+        z = lazy_add([z, ds])
+        v = lazy_add([v, dv])
+        inter["z%d" % i] = z.values
+        inter["v%d" % i] = v.values
+    out = pooling_nodes(z, node_pooling)
+    out = mlp(out, [(params["output_mlp/%d/kernel" % k], params.get("output_mlp/%d/bias" % k), output_mlp_act[k])
+                    for k in range(len(output_mlp_act))])
+    if return_intermediate:
+        return out, inter
+    return out
+
+
+# ----------------------------------------------------------------------------------------
+# kgcnn/layers/conv/gcn_conv.py, kgcnn/literature/GCN.py
+# ----------------------------------------------------------------------------------------
+
+def gcn_layer(node, edges, idx, p, act="relu", pooling_method="sum", normalize_by_weights=False,
+              is_sorted=False, has_unconnected=True):
+    """``GCN.call``, kgcnn/layers/conv/gcn_conv.py:85-90."""
+    no = dense(node, p["kernel"], p.get("bias"), "linear")
+    no = gather_nodes_outgoing(no, idx)
+    nu = pooling_weighted_local_edges(node, no, idx, edges, pooling_method=pooling_method,
+                                      normalize_by_weights=normalize_by_weights, is_sorted=is_sorted,
+                                      has_unconnected=has_unconnected)
+    return R(activation(act, nu.values), nu.row_splits)
+
+
+def gcn_forward(params, node_attr, edge_weights, idx, depth=3, act="relu", pooling_method="sum",
+                output_mlp_act=("relu", "relu", "softmax"), return_intermediate=False):
+    """``kgcnn.literature.GCN.make_model`` forward with ``output_embedding='node'``,
+    kgcnn/literature/GCN.py:95-109.  Returns the ragged node output's values."""
+    inter = {}
+    n = dense(node_attr, params["dense0/kernel"], params["dense0/bias"], "linear")
+    for i in range(depth):
+        n = gcn_layer(n, edge_weights, idx, _sub(params, "gcn%d/" % i), act=act, pooling_method=pooling_method)
+        inter["n%d" % i] = n.values
+    out = mlp(n, [(params["output_mlp/%d/kernel" % k], params.get("output_mlp/%d/bias" % k), output_mlp_act[k])
+                  for k in range(len(output_mlp_act))])
+    if return_intermediate:
+        return out, inter
+    return out
+
+
+# ----------------------------------------------------------------------------------------
+# kgcnn/layers/casting.py
+# ----------------------------------------------------------------------------------------
+
+def ragged_to_padded(r, default_value=0):
+    """``ChangeTensorType(ragged -> padded/mask)``, kgcnn/layers/casting.py:79-84: ``(padded, mask)``."""
+    lens = row_lengths(r)
+    g = len(lens)
+    nmax = int(lens.max()) if g > 0 else 0
+    padded = np.full((g, nmax) + r.values.shape[1:], default_value, dtype=r.values.dtype)
+    mask = np.zeros((g, nmax) + r.values.shape[1:], dtype=r.values.dtype)
+    for i in range(g):
+        padded[i, :lens[i]] = r.values[r.row_splits[i]:r.row_splits[i + 1]]
+        mask[i, :lens[i]] = 1
+    return padded, mask
+
+
+def to_dtype(tree, dtype):
+    """Cast every floating array of a dict / R / list to ``dtype`` (float64 twin for error budgets)."""
+    if isinstance(tree, dict):
+        return {k: to_dtype(v, dtype) for k, v in tree.items()}
+    if isinstance(tree, R):
+        return R(to_dtype(tree.values, dtype), tree.row_splits)
+    if isinstance(tree, (list, tuple)):
+        return type(tree)(to_dtype(v, dtype) for v in tree)
+    a = np.asarray(tree)
+    if np.issubdtype(a.dtype, np.floating):
+        return a.astype(dtype)
+    return a

@@ -1,0 +1,109 @@
+"""Cross-checks the NumPy oracle with an independent torch-CPU formulation (index_select / index_add_ /
+scatter_reduce) and with its own frozen outputs.  These results are 'parity unpinned' w.r.t. TensorFlow."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from gcnn_keras_amd import synth
+from oracle import kgcnn_oracle as ko
+
+
+def _rand_case(seed, n_graphs=5, f=7, sort=False):
+    rng = np.random.default_rng(seed)
+    n_len = rng.integers(0, 6, size=n_graphs)
+    n_len[rng.integers(n_graphs)] = 4
+    e_len = np.array([rng.integers(0, 9) if n > 0 else 0 for n in n_len])
+    idx = np.concatenate([rng.integers(0, max(n, 1), size=(m, 2)) for n, m in zip(n_len, e_len)]).astype(np.int64)
+    if sort:
+        parts, o = [], 0
+        for m in e_len:
+            blk = idx[o:o + m]
+            parts.append(blk[np.lexsort((blk[:, 1], blk[:, 0]))])
+            o += m
+        idx = np.concatenate(parts) if parts else idx
+    nodes = ko.ragged_from_row_lengths(rng.normal(size=(n_len.sum(), f)).astype(np.float32), n_len)
+    edges = ko.ragged_from_row_lengths(rng.normal(size=(e_len.sum(), f)).astype(np.float32), e_len)
+    w = ko.ragged_from_row_lengths(rng.uniform(0.1, 1, size=(e_len.sum(), 1)).astype(np.float32), e_len)
+    return nodes, edges, ko.ragged_from_row_lengths(idx, e_len), w
+
+
+@pytest.mark.parametrize("method", ["sum", "mean", "max", "min"])
+@pytest.mark.parametrize("seed", [0, 1, 2])
+def test_pooling_local_edges_vs_torch(method, seed):
+    nodes, edges, idx, _ = _rand_case(seed)
+    out = ko.pooling_local_edges(nodes, edges, idx, method).values
+    recv = torch.from_numpy(ko._shift(nodes, idx)[:, 0])
+    e = torch.from_numpy(edges.values)
+    n = nodes.values.shape[0]
+    red = {"sum": "sum", "mean": "mean", "max": "amax", "min": "amin"}[method]
+    ref = torch.zeros(n, e.shape[1]).scatter_reduce(0, recv[:, None].expand_as(e), e, red, include_self=False)
+    np.testing.assert_allclose(out, ref.numpy(), rtol=1e-6, atol=1e-6)
+    assert out.shape == (n, e.shape[1])
+
+
+def test_gather_and_weighted_vs_torch():
+    nodes, edges, idx, w = _rand_case(5)
+    sh = torch.from_numpy(ko._shift(nodes, idx))
+    x = torch.from_numpy(nodes.values)
+    g = ko.gather_nodes(nodes, idx).values
+    ref = torch.cat([x.index_select(0, sh[:, 0]), x.index_select(0, sh[:, 1])], dim=1)
+    assert np.array_equal(g, ref.numpy())
+    out = ko.pooling_weighted_local_edges(nodes, edges, idx, w, "sum", normalize_by_weights=True).values
+    num = torch.zeros(x.shape[0], x.shape[1]).index_add_(0, sh[:, 0], torch.from_numpy(edges.values * w.values))
+    den = torch.zeros(x.shape[0], 1).index_add_(0, sh[:, 0], torch.from_numpy(w.values))
+    ref = torch.where(den == 0, torch.zeros_like(num), num / den)
+    np.testing.assert_allclose(out, ref.numpy(), rtol=1e-6, atol=1e-6)
+
+
+def test_pooling_nodes_drops_trailing_empty_graphs():
+    # kgcnn/layers/pooling.py:215-219: rows = max(rowid) + 1 (SURVEY 8a note 6)
+    vals = np.arange(12, dtype=np.float32).reshape(6, 2)
+    r = ko.R(vals, np.array([0, 2, 2, 6, 6, 6], dtype=np.int64))
+    out = ko.pooling_nodes(r, "sum")
+    assert out.shape == (3, 2)
+    assert np.array_equal(out[1], [0, 0])
+    assert np.array_equal(out[0], vals[:2].sum(0))
+
+
+def test_unsorted_equals_sorted_semantics():
+    nodes, edges, idx, _ = _rand_case(7, sort=True)
+    a = ko.pooling_local_edges(nodes, edges, idx, "sum", is_sorted=True).values
+    b = ko.pooling_local_edges(nodes, edges, idx, "sum", is_sorted=False).values
+    assert np.array_equal(a, b)
+
+
+def test_softplus_thresholds():
+    x = np.array([-100, -20, -13.9, -1, 0, 1, 13.9, 20, 100], dtype=np.float32)
+    ref = np.log1p(np.exp(x.astype(np.float64)))
+    np.testing.assert_allclose(ko.softplus(x), ref, rtol=2e-7, atol=1e-30)
+    assert ko.shifted_softplus(np.zeros(1, np.float32))[0] == 0
+
+
+def test_frozen_model_outputs(golden_dir):
+    b = synth.qm9_like_batch(num_graphs=6, seed=11)
+    p = synth.schnet_params(seed=7, random_bias=True)
+    out = ko.schnet_forward(p, ko.R(b["node_number"], b["node_splits"]), ko.R(b["node_coordinates"], b["node_splits"]),
+                            ko.R(b["edge_indices"], b["edge_splits"]), depth=3)
+    np.testing.assert_allclose(out, np.load(os.path.join(golden_dir, "frozen_schnet_small.npz"))["out"],
+                               rtol=1e-5, atol=1e-6)
+    # float64 twin: the float32 oracle stays within 1e-5 relative of it
+    out64 = ko.schnet_forward(ko.to_dtype(p, np.float64), ko.R(b["node_number"], b["node_splits"]),
+                              ko.R(b["node_coordinates"].astype(np.float64), b["node_splits"]),
+                              ko.R(b["edge_indices"], b["edge_splits"]), depth=3)
+    assert np.max(np.abs(out - out64)) <= 1e-5 * np.max(np.abs(out64))
+
+    b = synth.md17_like_batch(num_graphs=3, seed=12)
+    p = synth.painn_params(seed=8, random_bias=True)
+    out = ko.painn_forward(p, ko.R(b["node_number"], b["node_splits"]), ko.R(b["node_coordinates"], b["node_splits"]),
+                           ko.R(b["edge_indices"], b["edge_splits"]), depth=3, equiv_method="eps")
+    np.testing.assert_allclose(out, np.load(os.path.join(golden_dir, "frozen_painn_small.npz"))["out"],
+                               rtol=1e-5, atol=1e-6)
+
+    g = synth.cora_like_graph(num_nodes=120, num_features=40, seed=13, drop_pairs=9)
+    p = synth.gcn_params(seed=9, in_features=40, random_bias=True)
+    out = ko.gcn_forward(p, ko.R(g["node_attributes"], g["node_splits"]), ko.R(g["edge_weights"], g["edge_splits"]),
+                         ko.R(g["edge_indices"], g["edge_splits"]))
+    np.testing.assert_allclose(out.values, np.load(os.path.join(golden_dir, "frozen_gcn_small.npz"))["out"],
+                               rtol=1e-5, atol=1e-6)
