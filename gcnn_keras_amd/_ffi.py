@@ -1,0 +1,144 @@
+"""ctypes binding of libmpengine.so (the C ABI declared in include/mpengine.h).
+
+This is the only place where Python meets the engine: plain pointers and sizes cross the boundary, torch is used
+for device memory and streams only.  There is NO CPU fallback: if the shared library is missing or a tensor is
+not on a HIP device, the call fails loudly.
+"""
+import ctypes
+import os
+from ctypes import c_char_p, c_float, c_int, c_int64, c_size_t, c_void_p
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "csrc", "libmpengine.so")
+
+MP_OK, MP_EINVAL, MP_EINDEX, MP_EHIP, MP_ENOTSUP = 0, -1, -2, -3, -4
+MP_SUM, MP_MEAN, MP_MAX, MP_MIN = 0, 1, 2, 3
+MP_ADD, MP_SUB, MP_MUL = 0, 1, 2
+MP_FLAG_OOB, MP_FLAG_UNSORTED_COL0, MP_FLAG_UNSORTED_COL1 = 1, 2, 4
+
+ACTIVATION_CODES = {
+    None: 0, "linear": 0, "relu": 1, "kgcnn>shifted_softplus": 2, "shifted_softplus": 2, "softplus": 3,
+    "swish": 4, "sigmoid": 5, "tanh": 6, "kgcnn>leaky_relu": 7, "leaky_relu": 7,
+}
+
+P = c_void_p
+# name -> argtypes (restype is int unless listed in _RESTYPES); mirrors include/mpengine.h one to one.
+_SIGNATURES = {
+    "mp_last_error": [],
+    "mp_version": [],
+    "mp_device_info": [c_char_p, c_int, P, P],
+    "mp_graph_begin": [P],
+    "mp_graph_end": [P, P],
+    "mp_graph_launch": [P, P],
+    "mp_graph_destroy": [P],
+    "mp_event_create": [P],
+    "mp_event_record": [P, P],
+    "mp_event_elapsed_ms": [P, P, P],
+    "mp_event_destroy": [P],
+    "mp_shift_index_i64": [P, c_int64, c_int, P, P, c_int64, c_int, P, P],
+    "mp_index_prepare_i64": [P, c_int64, c_int, P, P, c_int64, c_int64, P, P, P],
+    "mp_csr_from_sorted_i32": [P, c_int64, c_int64, P, P],
+    "mp_sort_workspace_bytes": [c_int64, P],
+    "mp_sort_segments_i32": [P, c_int64, P, P, P, c_size_t, P],
+    "mp_gather_rows_f32": [P, c_int64, c_int64, P, c_int64, c_int, P, P, P],
+    "mp_gather_rows_i64_f32": [P, c_int64, c_int64, P, c_int64, c_int, c_int, P, P, c_int64, P, P],
+    "mp_repeat_rows_f32": [P, P, c_int64, c_int64, c_int64, P, P],
+    "mp_embedding_f32": [P, c_int64, c_int64, P, c_int64, P, P, P],
+    "mp_segment_reduce_csr_f32": [c_int, P, c_int64, c_int64, P, P, c_int64, P, c_int, P, P],
+    "mp_pool_graph_f32": [c_int, P, P, c_int64, c_int64, P, P, P],
+    "mp_segment_softmax_csr_f32": [P, c_int64, c_int64, P, P, c_int64, P, P],
+    "mp_scatter_relational_f32": [c_int, P, c_int64, c_int64, P, P, c_int64, c_int64, P, P],
+    "mp_dense_f32": [P, c_int64, c_int64, P, P, c_int64, c_int, c_float, P, P],
+    "mp_activation_f32": [c_int, c_float, P, c_int64, P, P],
+    "mp_softmax_rows_f32": [P, c_int64, c_int64, P, P],
+    "mp_binary_f32": [c_int, P, P, P, P, c_int64, c_int64, c_int64, P, P],
+    "mp_copy_cols_f32": [P, c_int64, c_int64, P, c_int64, c_int64, c_int64, c_int64, P],
+    "mp_euclidean_norm_f32": [P, c_int64, c_int64, c_int64, c_int, P, P],
+    "mp_scalar_product_f32": [P, P, c_int64, c_int64, c_int64, P, P],
+    "mp_gauss_basis_f32": [P, c_int64, c_int, c_float, c_float, c_float, P, P],
+    "mp_bessel_basis_f32": [P, c_int64, P, c_int, c_float, c_int, P, P],
+    "mp_cos_cutoff_f32": [P, c_int64, c_float, P, P],
+    "mp_edge_geometry_f32": [P, c_int64, P, P, c_int64, P, P, P],
+    "mp_ragged_to_padded_f32": [P, P, c_int64, c_int64, c_int64, P, P, P],
+}
+_RESTYPES = {"mp_last_error": c_char_p}
+
+_lib = None
+
+
+class EngineError(RuntimeError):
+    pass
+
+
+def declared_symbols():
+    """Names of every entry point declared in include/mpengine.h (checked by tests/test_abi.py)."""
+    return sorted(_SIGNATURES)
+
+
+def lib():
+    """Load libmpengine.so once.  Raises if it was not built (run ``python -c 'import __graft_entry__ as g; g.build()'``)."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise EngineError("libmpengine.so not found at %s - build it with __graft_entry__.build() "
+                              "(there is no CPU fallback)" % LIB_PATH)
+        handle = ctypes.CDLL(LIB_PATH)
+        for name, argtypes in _SIGNATURES.items():
+            fn = getattr(handle, name)
+            fn.argtypes = argtypes
+            fn.restype = _RESTYPES.get(name, c_int)
+        _lib = handle
+    return _lib
+
+
+def check(rc):
+    if rc == MP_OK:
+        return
+    msg = lib().mp_last_error().decode("utf-8", "replace")
+    if rc == MP_EINVAL:
+        raise ValueError(msg)
+    if rc == MP_EINDEX:
+        raise IndexError(msg)
+    raise EngineError("libmpengine status %d: %s" % (rc, msg))
+
+
+def require_device(*tensors):
+    for t in tensors:
+        if t is not None and not t.is_cuda:
+            raise EngineError("gcnn_keras_amd ops run on an MI355X only: got a %s tensor (no CPU fallback)" % t.device)
+
+
+def ptr(t):
+    """Device pointer of a contiguous torch tensor (None -> NULL)."""
+    if t is None:
+        return None
+    if not t.is_contiguous():
+        raise ValueError("engine buffers must be contiguous")
+    return c_void_p(t.data_ptr())
+
+
+def stream():
+    """hipStream_t of torch's current stream (torch is plumbing: memory + streams)."""
+    return c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def call(name, *args):
+    check(getattr(lib(), name)(*args))
+
+
+def activation_code(name):
+    if isinstance(name, dict):
+        name = name.get("class_name", name.get("name"))
+    if name not in ACTIVATION_CODES:
+        raise ValueError("Activation %r is not supported by the engine" % (name,))
+    return ACTIVATION_CODES[name]
+
+
+def int64_array(values):
+    return (c_int64 * len(values))(*values)
+
+
+def int32_array(values):
+    return (ctypes.c_int32 * len(values))(*values)

@@ -1,0 +1,76 @@
+// Shared host-side helpers of libmpengine (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdint>
+#include <cstdio>
+
+#include "../../include/mpengine.h"
+
+namespace mp {
+
+void set_error(const char* fmt, ...);
+
+inline hipStream_t as_stream(mpStream_t s) { return reinterpret_cast<hipStream_t>(s); }
+
+inline int check_launch(const char* what) {
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) {
+    set_error("%s: HIP launch failed: %s", what, hipGetErrorString(e));
+    return MP_EHIP;
+  }
+  return MP_OK;
+}
+
+inline int64_t ceil_div(int64_t a, int64_t b) { return (a + b - 1) / b; }
+
+// Grid for a grid-stride elementwise kernel: enough blocks to fill 256 CUs x 8, never more than the work.
+inline unsigned grid_for(int64_t work_items, int block = 256) {
+  int64_t blocks = ceil_div(work_items, block);
+  if (blocks < 1) blocks = 1;
+  if (blocks > 256 * 8) blocks = 256 * 8;
+  return static_cast<unsigned>(blocks);
+}
+
+}  // namespace mp
+
+#define MP_REQUIRE(cond, ...)        \
+  do {                               \
+    if (!(cond)) {                   \
+      mp::set_error(__VA_ARGS__);    \
+      return MP_EINVAL;              \
+    }                                \
+  } while (0)
+
+#define MP_HIP(call)                                                          \
+  do {                                                                        \
+    hipError_t _e = (call);                                                   \
+    if (_e != hipSuccess) {                                                   \
+      mp::set_error("%s failed: %s", #call, hipGetErrorString(_e));           \
+      return MP_EHIP;                                                         \
+    }                                                                         \
+  } while (0)
+
+// Activation functors shared by the dense epilogue and the standalone activation kernel.
+// shifted_softplus restates kgcnn/ops/activ.py:15 with TF's thresholded softplus
+// (x > -thr -> x ; x < thr -> exp(x) ; else log1p(exp(x)), thr = log(eps_f32) + 2).
+__device__ __forceinline__ float mp_softplus(float x) {
+  const float thr = -13.942385f;  // logf(1.1920929e-07f) + 2
+  float ex = expf(x);
+  float mid = log1pf(ex);
+  return x > -thr ? x : (x < thr ? ex : mid);
+}
+
+__device__ __forceinline__ float mp_apply_act(int act, float alpha, float v) {
+  switch (act) {
+    case MP_ACT_RELU: return fmaxf(v, 0.0f);
+    case MP_ACT_SHIFTED_SOFTPLUS: return mp_softplus(v) - 0.6931471805599453f;
+    case MP_ACT_SOFTPLUS: return mp_softplus(v);
+    case MP_ACT_SWISH: return v * (1.0f / (1.0f + expf(-v)));
+    case MP_ACT_SIGMOID: return 1.0f / (1.0f + expf(-v));
+    case MP_ACT_TANH: return tanhf(v);
+    case MP_ACT_LEAKY_RELU: return v >= 0.0f ? v : alpha * v;
+    default: return v;
+  }
+}

@@ -1,0 +1,145 @@
+// Keras Dense on flat ragged values (kgcnn/layers/modules.py:74-87): out = act(x @ W + b).
+//
+// FP32-in / FP32-accumulate MFMA (v_mfma_f32_32x32x2_f32): exact f32 products, k-ordered fma chain, which keeps
+// the 1e-5 relative budget of BASELINE.json with room to spare (no xf32/TF32 on gfx950).  Generic in R, K, U
+// (SchNet (M,20)x(20,128), PaiNN (N,3,128)x(128,384), GCN (2708,1433)x(1433,64), heads with U = 1 or 7).
+// 64x64 output tile per 256-thread workgroup = 2x2 waves of one 32x32 accumulator each, BK = 32, operands staged
+// through LDS (A padded to 33 floats per row so the 32 rows a half-wave reads for one k hit 32 different banks,
+// W rows read contiguously), next tile's global loads issued before the MFMA loop of the current one.
+// The fused SchNet kernels (mp_cfconv.hip / mp_schnet_node.hip) are the throughput path; this kernel serves
+// the layer-by-layer API and the GEMMs that are not worth fusing.
+#include "mp_common.h"
+
+namespace {
+
+using floatx16 = __attribute__((ext_vector_type(16))) float;
+
+constexpr int BM = 64, BN = 64, BK = 32;
+constexpr int A_LD = BK + 1;
+
+__global__ __launch_bounds__(256) void dense_mfma_kernel(const float* __restrict__ x, int64_t R, int64_t K,
+                                                         const float* __restrict__ W, const float* __restrict__ b,
+                                                         int64_t U, int act, float alpha, float* __restrict__ out) {
+  __shared__ float As[BM * A_LD];
+  __shared__ float Bs[BK * BN];
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = tid >> 6;
+  const int wr = wave >> 1, wc = wave & 1;
+  const int64_t row0 = static_cast<int64_t>(blockIdx.x) * BM;
+  const int64_t col0 = static_cast<int64_t>(blockIdx.y) * BN;
+
+  floatx16 acc;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) acc[i] = 0.0f;
+
+  float ra[8], rb[8];
+  auto load_tile = [&](int64_t k0) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const int idx = tid + i * 256;
+      const int ar = idx >> 5, ac = idx & 31;
+      const int64_t gr = row0 + ar, gk = k0 + ac;
+      ra[i] = (gr < R && gk < K) ? x[gr * K + gk] : 0.0f;
+      const int br = idx >> 6, bc = idx & 63;
+      const int64_t gk2 = k0 + br, gc = col0 + bc;
+      rb[i] = (gk2 < K && gc < U) ? W[gk2 * U + gc] : 0.0f;
+    }
+  };
+  auto store_tile = [&]() {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const int idx = tid + i * 256;
+      As[(idx >> 5) * A_LD + (idx & 31)] = ra[i];
+      Bs[idx] = rb[i];
+    }
+  };
+
+  const int64_t ktiles = (K + BK - 1) / BK;
+  load_tile(0);
+  for (int64_t t = 0; t < ktiles; ++t) {
+    store_tile();
+    __syncthreads();
+    if (t + 1 < ktiles) load_tile((t + 1) * BK);
+    const float* a_ptr = As + (wr * 32 + (lane & 31)) * A_LD + (lane >> 5);
+    const float* b_ptr = Bs + (lane >> 5) * BN + wc * 32 + (lane & 31);
+#pragma unroll
+    for (int kk = 0; kk < BK / 2; ++kk) {
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a_ptr[kk * 2], b_ptr[kk * 2 * BN], acc, 0, 0, 0);
+    }
+    __syncthreads();
+  }
+
+  const int64_t col = col0 + wc * 32 + (lane & 31);
+  if (col < U) {
+    const float bias = b ? b[col] : 0.0f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int64_t row = row0 + wr * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+      if (row < R) out[row * U + col] = mp_apply_act(act, alpha, acc[r] + bias);
+    }
+  }
+}
+
+__global__ void activation_kernel(int act, float alpha, const float* __restrict__ x, int64_t n,
+                                  float* __restrict__ out) {
+  const int64_t stride = static_cast<int64_t>(gridDim.x) * blockDim.x;
+  for (int64_t i = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x; i < n; i += stride)
+    out[i] = mp_apply_act(act, alpha, x[i]);
+}
+
+// Row softmax (Keras "softmax" on the last axis; GCN node classifier, kgcnn/training/hyper/hyper_cora_lu.py:144).
+// One 64-lane wave per row, lanes stride the row, wave-wide max / sum by xor shuffles.
+__global__ void softmax_rows_kernel(const float* __restrict__ x, int64_t R, int64_t C, float* __restrict__ out) {
+  const int lane = threadIdx.x & 63;
+  const int64_t wave_global = (static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x) >> 6;
+  const int64_t nwaves = (static_cast<int64_t>(gridDim.x) * blockDim.x) >> 6;
+  for (int64_t r = wave_global; r < R; r += nwaves) {
+    const float* row = x + r * C;
+    float mx = -INFINITY;
+    for (int64_t c = lane; c < C; c += 64) mx = fmaxf(mx, row[c]);
+    for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));
+    float sum = 0.0f;
+    for (int64_t c = lane; c < C; c += 64) sum += expf(row[c] - mx);
+    for (int o = 32; o > 0; o >>= 1) sum += __shfl_xor(sum, o, 64);
+    for (int64_t c = lane; c < C; c += 64) out[r * C + c] = expf(row[c] - mx) / sum;
+  }
+}
+
+}  // namespace
+
+extern "C" {
+
+int mp_dense_f32(const float* x, int64_t R, int64_t K, const float* W, const float* b, int64_t U, int act,
+                 float act_alpha, float* out, mpStream_t stream) {
+  MP_REQUIRE(R >= 0 && K >= 1 && U >= 1, "mp_dense_f32: bad sizes R=%lld K=%lld U=%lld", (long long)R, (long long)K,
+             (long long)U);
+  MP_REQUIRE(act >= MP_ACT_LINEAR && act <= MP_ACT_LEAKY_RELU, "mp_dense_f32: unknown activation %d", act);
+  if (R == 0) return MP_OK;
+  MP_REQUIRE(x && W && out, "mp_dense_f32: null pointer");
+  const int64_t gy = mp::ceil_div(R, BM), gx = mp::ceil_div(U, BN);
+  MP_REQUIRE(gx <= 65535 && gy < (int64_t{1} << 31), "mp_dense_f32: grid too large");
+  dim3 grid(static_cast<unsigned>(gy), static_cast<unsigned>(gx));
+  dense_mfma_kernel<<<grid, 256, 0, mp::as_stream(stream)>>>(x, R, K, W, b, U, act, act_alpha, out);
+  return mp::check_launch("mp_dense_f32");
+}
+
+int mp_activation_f32(int act, float act_alpha, const float* x, int64_t n, float* out, mpStream_t stream) {
+  MP_REQUIRE(n >= 0, "mp_activation_f32: bad size");
+  MP_REQUIRE(act >= MP_ACT_LINEAR && act <= MP_ACT_LEAKY_RELU, "mp_activation_f32: unknown activation %d", act);
+  if (n == 0) return MP_OK;
+  MP_REQUIRE(x && out, "mp_activation_f32: null pointer");
+  activation_kernel<<<mp::grid_for(n), 256, 0, mp::as_stream(stream)>>>(act, act_alpha, x, n, out);
+  return mp::check_launch("mp_activation_f32");
+}
+
+int mp_softmax_rows_f32(const float* x, int64_t R, int64_t C, float* out, mpStream_t stream) {
+  MP_REQUIRE(R >= 0 && C >= 1, "mp_softmax_rows_f32: bad sizes");
+  if (R == 0) return MP_OK;
+  MP_REQUIRE(x && out, "mp_softmax_rows_f32: null pointer");
+  softmax_rows_kernel<<<mp::grid_for(R * 64), 256, 0, mp::as_stream(stream)>>>(x, R, C, out);
+  return mp::check_launch("mp_softmax_rows_f32");
+}
+
+}  // extern "C"

@@ -1,0 +1,112 @@
+"""SchNet model builder (mirror of kgcnn/literature/Schnet.py:24-148, ``make_model``; crystal variant out of scope).
+
+``make_model(**kwargs)`` accepts the reference's keyword dictionary (validated against ``model_default`` by
+``update_model_kwargs``) and returns a callable model taking ``[node_attributes, node_coordinates, edge_indices]``
+as ragged tensors.  Weights are created in constructor order, so ``model.set_weights`` accepts the list that
+``gcnn_keras_amd.synth.schnet_params`` / a Keras ``get_weights()`` of the reference model produce.
+"""
+from ..layers.casting import ChangeTensorType
+from ..layers.conv.schnet_conv import SchNetInteraction
+from ..layers.geom import GaussBasisLayer, NodeDistanceEuclidean, NodePosition
+from ..layers.mlp import MLP, GraphMLP
+from ..layers.modules import Dense, OptionalInputEmbedding
+from ..layers.pooling import PoolingNodes
+from ..model.utils import Model, update_model_kwargs
+
+__model_version__ = "2022.11.25"
+
+model_default = {
+    "name": "Schnet",
+    "inputs": [{"shape": (None,), "name": "node_attributes", "dtype": "float32", "ragged": True},
+               {"shape": (None, 3), "name": "node_coordinates", "dtype": "float32", "ragged": True},
+               {"shape": (None, 2), "name": "edge_indices", "dtype": "int64", "ragged": True}],
+    "input_embedding": {"node": {"input_dim": 95, "output_dim": 64}},
+    "make_distance": True, "expand_distance": True,
+    "interaction_args": {"units": 128, "use_bias": True,
+                         "activation": "kgcnn>shifted_softplus", "cfconv_pool": "sum"},
+    "node_pooling_args": {"pooling_method": "sum"},
+    "depth": 4,
+    "gauss_args": {"bins": 20, "distance": 4, "offset": 0.0, "sigma": 0.4},
+    "verbose": 10,
+    "last_mlp": {"use_bias": [True, True], "units": [128, 64],
+                 "activation": ["kgcnn>shifted_softplus", "kgcnn>shifted_softplus"]},
+    "output_embedding": "graph", "output_to_tensor": True,
+    "use_output_mlp": True,
+    "output_mlp": {"use_bias": [True, True], "units": [64, 1],
+                   "activation": ["kgcnn>shifted_softplus", "linear"]}
+}
+
+
+@update_model_kwargs(model_default)
+def make_model(inputs: list = None, input_embedding: dict = None, make_distance: bool = None,
+               expand_distance: bool = None, gauss_args: dict = None, interaction_args: dict = None,
+               node_pooling_args: dict = None, depth: int = None, name: str = None, verbose: int = None,
+               last_mlp: dict = None, output_embedding: str = None, use_output_mlp: bool = None,
+               output_to_tensor: bool = None, output_mlp: dict = None):
+    r"""Build SchNet (kgcnn/literature/Schnet.py:46-148).  Inputs of the returned model:
+    ``[node_attributes, edge_distance | node_coordinates, edge_indices]`` ragged; output ``(batch, L)`` tensor for
+    ``output_embedding="graph"``."""
+    if output_embedding not in ("graph", "node"):
+        raise ValueError("Unsupported output embedding for mode `SchNet`")
+
+    embed = OptionalInputEmbedding(**input_embedding["node"], use_embedding=len(inputs[0]["shape"]) < 2)
+    lay_pos = NodePosition() if make_distance else None
+    lay_dist = NodeDistanceEuclidean() if make_distance else None
+    lay_gauss = GaussBasisLayer(**gauss_args) if expand_distance else None
+    dense0 = Dense(interaction_args["units"], activation="linear")
+    interactions = [SchNetInteraction(**interaction_args) for _ in range(depth)]
+    last = GraphMLP(**last_mlp)
+    pool = PoolingNodes(**node_pooling_args) if output_embedding == "graph" else None
+    out_mlp = None
+    if use_output_mlp:
+        out_mlp = MLP(**output_mlp) if output_embedding == "graph" else GraphMLP(**output_mlp)
+    cast = ChangeTensorType(input_tensor_type="ragged", output_tensor_type="tensor") \
+        if (output_embedding == "node" and output_to_tensor) else None
+
+    def forward(model_inputs, **kwargs):
+        node_input, xyz_input, edge_index_input = model_inputs
+        n = embed(node_input)
+        edi = edge_index_input
+        if make_distance:
+            pos1, pos2 = lay_pos([xyz_input, edi])
+            ed = lay_dist([pos1, pos2])
+        else:
+            ed = xyz_input
+        if expand_distance:
+            ed = lay_gauss(ed)
+        n = dense0(n)
+        for inter in interactions:
+            n = inter([n, ed, edi])
+        n = last(n)
+        if output_embedding == "graph":
+            out = pool(n)
+            if use_output_mlp:
+                out = out_mlp(out)
+        else:
+            out = n
+            if use_output_mlp:
+                out = out_mlp(out)
+            if cast is not None:
+                out = cast(out)
+        return out
+
+    # Weights are created here, in the reference's construction order, so set_weights() works before a first call.
+    units = interaction_args["units"]
+    node_dim = input_embedding["node"]["output_dim"] if len(inputs[0]["shape"]) < 2 else inputs[0]["shape"][-1]
+    edge_dim = gauss_args["bins"] if expand_distance else inputs[1]["shape"][-1]
+    embed.ensure_built((None, None))
+    dense0.ensure_built((None, None, node_dim))
+    for inter in interactions:
+        inter.ensure_built([(None, None, units), (None, None, edge_dim), (None, None, 2)])
+    last.ensure_built((None, None, units))
+    last_dim = last_mlp["units"][-1] if isinstance(last_mlp["units"], (list, tuple)) else last_mlp["units"]
+    if out_mlp is not None:
+        out_mlp.ensure_built((None, last_dim) if output_embedding == "graph" else (None, None, last_dim))
+    layers = [embed, dense0] + interactions + [last] + ([out_mlp] if out_mlp is not None else [])
+    model = Model(name, forward, layers, config={"depth": depth, "interaction_args": interaction_args,
+                                                  "gauss_args": gauss_args, "last_mlp": last_mlp,
+                                                  "output_mlp": output_mlp, "node_pooling_args": node_pooling_args,
+                                                  "input_embedding": input_embedding,
+                                                  "output_embedding": output_embedding})
+    model.__kgcnn_model_version__ = __model_version__
+    return model

@@ -1,0 +1,182 @@
+/*
+ * mpengine.h - C ABI of the MI355X-native message-passing engine (libmpengine.so).
+ *
+ * Drop-in boundary for the ragged scatter-gather hot path of kgcnn (Tacitus523/gcnn_keras):
+ * every entry point replaces a short composition of TensorFlow ops inside one reference function,
+ * cited as file:line relative to the reference tree.  The reference has no FFI of its own (it is
+ * pure Python on TensorFlow); INTEGRATION.md shows the ctypes binding a maintainer adds to
+ * kgcnn/layers/{gather,pooling}.py to route through this library.
+ *
+ * Conventions
+ *  - All pointers are DEVICE pointers (HIP, gfx950) unless the name ends in _host.  Plain pointers and
+ *    sizes only; no framework types.  Values are float32 row-major; API indices / row_splits are int64
+ *    exactly as the reference's RaggedTensor delivers them (kgcnn/data/utils.py:129-157).
+ *  - Index convention: idx[e] = (i, j), column 0 = receiving node i, column 1 = sending node j
+ *    (reference README.md:66); indices are per-graph local ("sample" indexing, kgcnn/layers/base.py:42-43).
+ *  - Every call is asynchronous on the caller's stream (mpStream_t == hipStream_t), re-entrant, and keeps no
+ *    pointer after it returns.  The caller allocates every input, output and workspace buffer.
+ *  - Return: MP_OK or a negative status; mp_last_error() gives a thread-local message.  Host code maps
+ *    MP_EINVAL -> ValueError/TypeError, MP_EINDEX -> IndexError (TF InvalidArgumentError), MP_EHIP -> RuntimeError.
+ *  - Out-of-range indices never fault: they are clamped and recorded in a caller-provided device flag word
+ *    (the analogue of ragged_validate / TF-GPU's silent zero fill); the caller decides when to read the flag.
+ */
+#ifndef MPENGINE_H
+#define MPENGINE_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef void* mpStream_t; /* hipStream_t */
+
+enum mp_status { MP_OK = 0, MP_EINVAL = -1, MP_EINDEX = -2, MP_EHIP = -3, MP_ENOTSUP = -4 };
+
+/* kgcnn/ops/segment.py:39-46 names -> op */
+enum mp_reduce_op { MP_SUM = 0, MP_MEAN = 1, MP_MAX = 2, MP_MIN = 3 };
+
+/* Activations reachable from SchNet / PaiNN / GCN configs (kgcnn/ops/activ.py:6-15, Keras strings) */
+enum mp_activation {
+  MP_ACT_LINEAR = 0, MP_ACT_RELU = 1, MP_ACT_SHIFTED_SOFTPLUS = 2, MP_ACT_SOFTPLUS = 3, MP_ACT_SWISH = 4,
+  MP_ACT_SIGMOID = 5, MP_ACT_TANH = 6, MP_ACT_LEAKY_RELU = 7
+};
+
+enum mp_binary_op { MP_ADD = 0, MP_SUB = 1, MP_MUL = 2 };
+
+/* bits of the device flag word written by mp_index_prepare_i64 */
+enum mp_index_flag { MP_FLAG_OOB = 1, MP_FLAG_UNSORTED_COL0 = 2, MP_FLAG_UNSORTED_COL1 = 4 };
+
+/* ---------------------------------------------------------------- runtime -------------------------------- */
+const char* mp_last_error(void);
+int mp_version(void);
+/* Fills name (<= name_len bytes), CU count and LDS bytes per CU of the current HIP device. */
+int mp_device_info(char* name_host, int name_len, int* num_cu_host, int* lds_bytes_host);
+
+/* HIP-graph capture of a launch sequence on `stream` (replaces eager per-op dispatch of Keras/TF). */
+int mp_graph_begin(mpStream_t stream);
+int mp_graph_end(mpStream_t stream, void** graph_exec_out_host);
+int mp_graph_launch(void* graph_exec, mpStream_t stream);
+int mp_graph_destroy(void* graph_exec);
+
+/* HIP events on the caller's stream, for timing inside bench.py. */
+int mp_event_create(void** event_out_host);
+int mp_event_record(void* event, mpStream_t stream);
+int mp_event_elapsed_ms(void* start, void* stop, float* ms_out_host); /* synchronises on `stop` */
+int mp_event_destroy(void* event);
+
+/* ---------------------------------------------------------------- index ops ------------------------------ */
+/* kgcnn/ops/partition.py:97-162 partition_row_indexing (row_splits target, row_splits index):
+ * out[e,k] = idx[e,k] + direction * node_splits[graph_of_edge(e)], direction = +1 sample->batch, -1 batch->sample.
+ * Bit-exact int64. */
+int mp_shift_index_i64(const int64_t* idx, int64_t M, int K, const int64_t* node_splits, const int64_t* edge_splits,
+                       int64_t G, int direction, int64_t* out, mpStream_t stream);
+
+/* One pass over the API's (M,K) int64 sample indices that every gather / pooling call of the reference recomputes
+ * (partition.py:140-155 + gather.py:228 column pick): writes shifted int32 columns cols[k*M + e], and ORs
+ * MP_FLAG_* bits into *flags (caller zeroes it): out-of-range (clamped) and per-column sortedness (K<=2 tracked).
+ * N = total node count (node_splits[G]). */
+int mp_index_prepare_i64(const int64_t* idx, int64_t M, int K, const int64_t* node_splits, const int64_t* edge_splits,
+                         int64_t G, int64_t N, int32_t* cols, int32_t* flags, mpStream_t stream);
+
+/* CSR offsets ptr[0..N] from receiver-sorted segment ids (what tf.math.segment_* derives implicitly). */
+int mp_csr_from_sorted_i32(const int32_t* seg, int64_t M, int64_t N, int32_t* ptr, mpStream_t stream);
+
+/* Stable argsort by segment id = tf.argsort(stable=True) of kgcnn/layers/pooling.py:66; ws from mp_sort_workspace_bytes. */
+int mp_sort_workspace_bytes(int64_t M, size_t* bytes_out_host);
+int mp_sort_segments_i32(const int32_t* seg, int64_t M, int32_t* seg_sorted, int32_t* perm, void* ws, size_t ws_bytes,
+                         mpStream_t stream);
+
+/* ---------------------------------------------------------------- gather --------------------------------- */
+/* tf.gather(node, idx[:, col], axis=0) of kgcnn/layers/gather.py:83,228 on prepared int32 columns:
+ * out[(e*ncols + c)*row_elems + f] = x[cols[colsel[c]*M + e]*row_elems + f]; ncols=2, colsel={0,1} gives the
+ * GatherNodes concat layout [x_i || x_j] (gather.py:88-90).  Bit-exact copy. */
+int mp_gather_rows_f32(const float* x, int64_t N, int64_t row_elems, const int32_t* cols, int64_t M, int ncols,
+                       const int32_t* colsel_host, float* out, mpStream_t stream);
+
+/* Same, straight from the API's int64 sample indices with the shift fused (no prepared columns). */
+int mp_gather_rows_i64_f32(const float* x, int64_t N, int64_t row_elems, const int64_t* idx, int64_t M, int K,
+                           int col /* -1: all K columns, concat layout */, const int64_t* node_splits,
+                           const int64_t* edge_splits, int64_t G, float* out, mpStream_t stream);
+
+/* GatherState, kgcnn/layers/gather.py:363-369: out = repeat(state, row_lengths(splits), axis=0). */
+int mp_repeat_rows_f32(const float* state, const int64_t* splits, int64_t G, int64_t row_elems, int64_t N, float* out,
+                       mpStream_t stream);
+
+/* Embedding lookup of float node numbers (cast to int32 like Keras Embedding; kgcnn/layers/modules.py:526-528). */
+int mp_embedding_f32(const float* table, int64_t vocab, int64_t dim, const float* numbers, int64_t N, float* out,
+                     int32_t* flags, mpStream_t stream);
+
+/* ---------------------------------------------------------------- segment reduce ------------------------- */
+/* Sorted segment reduce of kgcnn/layers/pooling.py:63-76 + ops/segment.py:39-46 fused with the has_unconnected
+ * zero pad: out[n] = op_{e in [ptr[n], ptr[n+1])} (weight[r] *) data[r], r = perm ? perm[e] : e, accumulated
+ * sequentially in edge order (the order tf.math.segment_* uses after the stable sort); empty rows give 0 for
+ * every op.  weight (M) nullable multiplies BEFORE the reduce (pooling.py:152); normalize_by_weight divides by
+ * sum(weight) with divide_no_nan (pooling.py:164-165).  N_out rows are written. */
+int mp_segment_reduce_csr_f32(int op, const float* data, int64_t M, int64_t row_elems, const int32_t* ptr,
+                              const int32_t* perm, int64_t N_out, const float* weight, int normalize_by_weight,
+                              float* out, mpStream_t stream);
+
+/* PoolingEmbedding / PoolingNodes, kgcnn/layers/pooling.py:215-218: per-graph reduce driven by int64 row_splits
+ * (value_rowids never materialised).  Writes G rows (the host trims trailing empty graphs like TF does). */
+int mp_pool_graph_f32(int op, const float* x, const int64_t* row_splits, int64_t G, int64_t row_elems,
+                      const float* weight, float* out, mpStream_t stream);
+
+/* segment_softmax, kgcnn/ops/segment.py:5-24, on CSR segments: out[r] = exp(a[r]-max_seg)/sum_seg exp(...). */
+int mp_segment_softmax_csr_f32(const float* a, int64_t M, int64_t row_elems, const int32_t* ptr, const int32_t* perm,
+                               int64_t N, float* out, mpStream_t stream);
+
+/* tensor_scatter_nd_{add,max,min}, kgcnn/ops/scatter.py:18-23 as used by RelationalPoolingLocalEdges
+ * (pooling.py:658-666): out (N,R,F) must be zero-initialised by the caller; unsorted atomic scatter. */
+int mp_scatter_relational_f32(int op, const float* edges, int64_t M, int64_t row_elems, const int32_t* recv,
+                              const int32_t* relation, int64_t N, int64_t R, float* out, mpStream_t stream);
+
+/* ---------------------------------------------------------------- dense / elementwise -------------------- */
+/* Keras Dense on flat values, kgcnn/layers/modules.py:85: out = act(x @ W + b); x (R,K), W (K,U) row-major
+ * ("kernel" layout), b (U) nullable.  FP32 MFMA (v_mfma_f32_32x32x2_f32), k-ordered fma chain. */
+int mp_dense_f32(const float* x, int64_t R, int64_t K, const float* W, const float* b, int64_t U, int act,
+                 float act_alpha, float* out, mpStream_t stream);
+
+int mp_activation_f32(int act, float act_alpha, const float* x, int64_t n, float* out, mpStream_t stream);
+int mp_softmax_rows_f32(const float* x, int64_t R, int64_t C, float* out, mpStream_t stream);
+
+/* Broadcasting binary op on (R, D1, D2) views: operand strides in elements, 0 = broadcast
+ * (LazyAdd/LazySubtract/LazyMultiply of kgcnn/layers/modules.py:187-301, incl. PaiNN's (M,1,F)*(M,3,F)). */
+int mp_binary_f32(int op, const float* a, const int64_t* a_strides_host, const float* b, const int64_t* b_strides_host,
+                  int64_t R, int64_t D1, int64_t D2, float* out, mpStream_t stream);
+
+/* Strided 2-D column-block copy: dst[r*dst_ld + dst_off + c] = src[r*src_ld + src_off + c], c < C
+ * (LazyConcatenate modules.py:305-364 and SplitEmbedding painn_conv.py:329-340 on values). */
+int mp_copy_cols_f32(const float* src, int64_t src_ld, int64_t src_off, float* dst, int64_t dst_ld, int64_t dst_off,
+                     int64_t R, int64_t C, mpStream_t stream);
+
+/* ---------------------------------------------------------------- geometry ------------------------------- */
+/* EuclideanNorm._compute_euclidean_norm, kgcnn/layers/geom.py:181-193 on an (R, D, C) view reducing D:
+ * out (R,C) = [1/]sqrt(relu(sum_d x^2) [+eps]). flags: bit0 invert, bit1 add_eps, bit2 no_nan, bit3 square_norm. */
+int mp_euclidean_norm_f32(const float* x, int64_t R, int64_t D, int64_t C, int flags, float* out, mpStream_t stream);
+/* ScalarProduct, geom.py:261: out (R,C) = sum_d a*b. */
+int mp_scalar_product_f32(const float* a, const float* b, int64_t R, int64_t D, int64_t C, float* out,
+                          mpStream_t stream);
+/* GaussBasisLayer, geom.py:567-571. */
+int mp_gauss_basis_f32(const float* d, int64_t M, int bins, float distance, float sigma, float offset, float* out,
+                       mpStream_t stream);
+/* BesselBasisLayer, geom.py:772-785 (poly envelope, frequencies (num_radial) trainable weight). */
+int mp_bessel_basis_f32(const float* d, int64_t M, const float* frequencies, int num_radial, float cutoff,
+                        int envelope_exponent, float* out, mpStream_t stream);
+/* CosCutOffEnvelope, geom.py:831-837. */
+int mp_cos_cutoff_f32(const float* d, int64_t n, float cutoff, float* out, mpStream_t stream);
+
+/* Fused NodePosition -> LazySubtract -> EuclideanNorm (Schnet.py:116-117, PAiNN.py:116-118) on prepared columns:
+ * dist (M) = ||x_i - x_j||, dir (M,3) nullable = (x_i-x_j)*divide_no_nan(1, dist). */
+int mp_edge_geometry_f32(const float* xyz, int64_t N, const int32_t* recv, const int32_t* send, int64_t M,
+                         float* dist, float* dir, mpStream_t stream);
+
+/* ChangeTensorType ragged -> (padded, mask), kgcnn/layers/casting.py:79-84. */
+int mp_ragged_to_padded_f32(const float* values, const int64_t* row_splits, int64_t G, int64_t Nmax, int64_t row_elems,
+                            float* padded, float* mask, mpStream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MPENGINE_H */
