@@ -1,0 +1,161 @@
+#!/usr/bin/env python
+"""bench.py - edges/sec of a SchNet forward on QM9-shaped synthetic batches (BASELINE.json metric).
+
+    python bench.py --gpus N --steps K --warmup W            (N > 1: launched by torch.distributed.run, one rank per GPU)
+
+A step = one SchNet forward (kgcnn.literature.Schnet.make_model, F=128, depth 3, Gauss(20, 4.0, 0.4), sum pooling)
+over one resident batch of BASELINE config 2 (128 QM9-shaped graphs, seed 1234 + rank): raw API inputs (float node
+numbers, float32 coordinates, int64 (M,2) sample indices, int64 row_splits) are in HBM when the clock starts; the index
+preparation (shift, CSR), geometry, basis expansion, every interaction block, readout and output MLP are inside it.
+Graphs shard by rank with no data-path collective (weak scaling: every rank owns its own 128-graph batch); the only
+collective is one all-gather of the (G,1) predictions per step (RCCL over xGMI), as BASELINE.json's north_star states.
+
+Prints ONE JSON line (rank 0) with the contract keys plus `roofline` (dominant kernel, measured live with HIP events)
+and `cpu_baseline` (the NumPy oracle restating the reference's unfused TF op sequence, timed on the host cores).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0      # MI355X HBM3E spec (MI355X_MICROARCH.md chip table)
+FP32_MFMA_PEAK_TF = 157.3  # dense FP32 matrix peak (same table)
+
+
+def schnet_algorithmic_bytes(n, m, g, f=128, b=20, d=3):
+    """bytes = [16N + 16M + 4MB + 4NF] + D[8NF + 4MB + 16M] + [4NF + 4G]."""
+    return (16 * n + 16 * m + 4 * m * b + 4 * n * f) + d * (8 * n * f + 4 * m * b + 16 * m) + (4 * n * f + 4 * g)
+
+
+def schnet_flops(n, m, g, f=128, b=20, d=3):
+    """flops = M D [2(BF + F^2) + 2F] + N [2*64F + D 6F^2 + 2(F^2 + 64F)] + G 2(64^2 + 64)."""
+    return (m * d * (2 * (b * f + f * f) + 2 * f) + n * (2 * 64 * f + d * 6 * f * f + 2 * (f * f + 64 * f))
+            + g * 2 * (64 * 64 + 64))
+
+
+def cpu_baseline(batch, params, depth, budget_s=12.0):
+    """The oracle (a port of the reference's unfused op sequence) timed on this host; bounded to ~budget_s."""
+    from oracle import kgcnn_oracle as ko
+    inputs = (ko.R(batch["node_number"], batch["node_splits"]), ko.R(batch["node_coordinates"], batch["node_splits"]),
+              ko.R(batch["edge_indices"], batch["edge_splits"]))
+    ko.schnet_forward(params, *inputs, depth=depth)  # warm-up
+    times = []
+    t_end = time.perf_counter() + budget_s
+    while time.perf_counter() < t_end and len(times) < 50:
+        t0 = time.perf_counter()
+        ko.schnet_forward(params, *inputs, depth=depth)
+        times.append(time.perf_counter() - t0)
+    med = float(np.median(times))
+    m = int(batch["edge_splits"][-1])
+    try:
+        import threadpoolctl
+        blas_threads = max([p.get("num_threads", 1) for p in threadpoolctl.threadpool_info()] or [1])
+    except Exception:  # pragma: no cover
+        blas_threads = os.cpu_count() or 1
+    return {"value": m / med, "unit": "edges/s", "cores": int(blas_threads), "kind": "port",
+            "sample": "%d forwards of the same %d-graph batch (median %.1f ms); NumPy oracle: BLAS sgemm on %d threads, "
+                      "gather / segment ops single-threaded" % (len(times), len(batch["node_splits"]) - 1, med * 1e3,
+                                                                int(blas_threads))}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--graphs", type=int, default=128, help="graphs per GPU (BASELINE config 2 = 128)")
+    ap.add_argument("--mode", default="auto", choices=["auto", "fused", "layers"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    from gcnn_keras_amd import synth
+    from gcnn_keras_amd.engine import SchnetForward
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d: launch with torch.distributed.run --nproc-per-node %d"
+                         % (args.gpus, world, args.gpus))
+    torch.cuda.set_device(local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+
+    depth = 3
+    batch = synth.qm9_like_batch(num_graphs=args.graphs, seed=1234 + rank)
+    params = synth.schnet_params(seed=7)  # Keras defaults: glorot_uniform kernels, zero biases, U(-0.05, 0.05) embedding
+    n_nodes, n_edges, n_graphs = int(batch["node_splits"][-1]), int(batch["edge_splits"][-1]), args.graphs
+
+    fwd = SchnetForward(params, depth=depth, mode=args.mode)
+    fwd.load_batch(batch)
+    gathered = torch.empty((world * n_graphs, 1), dtype=torch.float32, device="cuda") if world > 1 else None
+
+    def step():
+        out = fwd.forward()
+        if world > 1:
+            dist.all_gather_into_tensor(gathered, out)
+        return out
+
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    t_max = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+    edges_all = torch.tensor([n_edges], dtype=torch.float64, device="cuda")
+    if world > 1:
+        dist.all_reduce(t_max, op=dist.ReduceOp.MAX)
+        dist.all_reduce(edges_all, op=dist.ReduceOp.SUM)
+    elapsed = float(t_max.item())
+    total_edges = float(edges_all.item())
+
+    fwd.check_flags()
+    roof = fwd.roofline(HBM_PEAK_GBS, FP32_MFMA_PEAK_TF)  # dominant kernel, timed with HIP events on its stream
+
+    if rank == 0:
+        ms_per_step = elapsed / args.steps * 1e3
+        value = total_edges * args.steps / elapsed
+        fwd_bytes = schnet_algorithmic_bytes(n_nodes, n_edges, n_graphs, d=depth)
+        fwd_flops = schnet_flops(n_nodes, n_edges, n_graphs, d=depth)
+        line = {
+            "metric": "edges/sec (SchNet fwd, QM9-shape batch)", "value": value, "unit": "edges/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "BASELINE config 2: SchNet forward (F=128, depth 3, Gauss 20) on %d QM9-shaped graphs "
+                                   "per GPU, N=%d nodes, M=%d directed edges on rank 0" % (n_graphs, n_nodes, n_edges),
+                       "graphs_per_gpu": n_graphs, "nodes": n_nodes, "edges": n_edges, "mode": fwd.mode,
+                       "sharding": "by graph, 1 all-gather of predictions per step" if world > 1 else "single GPU"},
+            "roofline": roof,
+            "forward_model": {"hbm_frac": fwd_bytes / (ms_per_step * 1e-3) / (HBM_PEAK_GBS * 1e9),
+                              "mfma_frac": fwd_flops / (ms_per_step * 1e-3) / (FP32_MFMA_PEAK_TF * 1e12),
+                              "algorithmic_bytes": fwd_bytes, "flops": fwd_flops, "kernels_per_forward": fwd.num_launches},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline(batch, params, depth)
+        print(json.dumps(line))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -62,6 +62,14 @@ _SIGNATURES = {
     "mp_cos_cutoff_f32": [P, c_int64, c_float, P, P],
     "mp_edge_geometry_f32": [P, c_int64, P, P, c_int64, P, P, P],
     "mp_ragged_to_padded_f32": [P, P, c_int64, c_int64, c_int64, P, P, P],
+    "mp_edge_prepare_i64_f32": [P, c_int64, P, P, c_int64, c_int64, P, P, P, P, P, P],
+    "mp_cfconv_fused_f32": [P, c_int64, P, c_int, P, P, P, P, P, P, P, c_int64, c_int, P, P],
+    "mp_cfconv_gauss_fused_f32": [P, c_int64, P, c_int, c_float, c_float, c_float, P, P, P, P, P, P, P, c_int64,
+                                  c_int, P, P],
+    "mp_schnet_node_in_f32": [P, c_int64, P, c_int, c_int, P, P, P, P, P, P],
+    "mp_schnet_node_update_f32": [P, c_int64, P, P, P, P, P, P, P, P],
+    "mp_schnet_node_last_f32": [P, c_int64, P, P, P, P, P, P, P, P, P, P, P],
+    "mp_schnet_readout_f32": [P, P, c_int64, P, P, P, P, P, P],
 }
 _RESTYPES = {"mp_last_error": c_char_p}
 
@@ -124,7 +132,16 @@ def stream():
     return c_void_p(torch.cuda.current_stream().cuda_stream)
 
 
+_launches = [0]
+
+
+def launch_count():
+    """Number of engine calls issued so far by this process (bench.py reports calls per forward)."""
+    return _launches[0]
+
+
 def call(name, *args):
+    _launches[0] += 1
     check(getattr(lib(), name)(*args))
 
 

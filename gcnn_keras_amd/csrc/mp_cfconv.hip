@@ -1,0 +1,319 @@
+// Fused SchNet continuous-filter convolution (kgcnn/layers/conv/schnet_conv.py:73-79):
+//
+//     w   = Dense(F, linear)(Dense(F, ssp)(rbf))         per-edge filter MLP  (B -> F -> F)
+//     x_j = GatherNodesOutgoing([x, idx])                 sender rows
+//     out = PoolingLocalEdges(sum)([x, x_j * w, idx])     segment-sum at the receiver
+//
+// in ONE kernel: neither the (M,F) hidden activations, the (M,F) filter, the gathered (M,F) sender rows nor
+// the (M,F) messages ever reach HBM (the reference materialises all of them, ~5.7 KB/edge/block; this kernel
+// reads 4 B (distance) or 4B B (rbf) + 8 B of indices per edge and adds each node row once or twice).
+//
+// Roofline: 2(BF + F^2) + 2F = 38.1 kflop per edge at F=128, B=20 against <= 100 B of compulsory traffic:
+// MFMA-bound (FP32 matrix peak 157.3 TF).  FP32-in/FP32-acc MFMA only (v_mfma_f32_32x32x2_f32) to hold the
+// 1e-5 budget - there is no TF32 on gfx950.
+//
+// Structure (F = 128 fixed; wave64; one wave owns a tile of 32 consecutive edges of the receiver-sorted list):
+//  * W1 (+ its bias as an extra input row) and W2 live in LDS for the whole persistent workgroup, stored
+//    [k][4*c + blk] so that one ds_read_b128 yields the operands of all four 32-wide feature blocks.
+//  * GEMM1 is computed TRANSPOSED, hT[f][e] = sum_b W1[b][f] rbf[e][b]: its accumulator then has the edge on the
+//    lane and the feature in the register, which is exactly the A-operand layout of GEMM2 (edge rows, k = feature)
+//    - the 128x32 hidden tile goes from one MFMA chain to the next in registers, no LDS round trip, no shuffles.
+//    The k order of GEMM2 is the accumulator's register order (a permutation of 0..127), the weights are read in
+//    that order.
+//  * GEMM2 w[e][j] leaves the output feature on the lane and the edge in the register: the sender gather
+//    x[send[e]][j] is a coalesced 128-B read per half wave, the multiply is in place.
+//  * Segment-sum: the 32x128 message tile is transposed through a private LDS slab ([feature][edge], padded),
+//    each lane then owns two features and walks the 32 edges in order with the (wave-uniform, scalar) receiver
+//    ids: interior segments are stored, the first and last segment of a tile - which may continue in the
+//    neighbouring tile - are added with one 256-B float atomic per 64 features.  A node whose edges span two
+//    tiles receives two adds onto a zero row, so the result is order independent (a + b == b + a); only
+//    receivers spanning three or more tiles (in-degree > 32) can differ in the last bit between runs.
+//  * The output buffer must be zero on entry (unconnected nodes keep 0 = the has_unconnected pad of
+//    kgcnn/layers/pooling.py:74-76).
+#include "mp_common.h"
+
+namespace {
+
+using floatx16 = __attribute__((ext_vector_type(16))) float;
+
+constexpr int F = 128;          // feature width of the fused kernel
+constexpr int TE = 32;          // edges per wave tile
+constexpr int T_LD = 36;        // padded edge stride of the per-wave transpose slab (floats)
+constexpr int MAX_KROWS = 34;   // W1 rows in LDS: B inputs + 1 bias row, padded to even (B <= 32)
+
+__device__ __forceinline__ int rowmap(int r, int hh) { return (r & 3) + 8 * (r >> 2) + 4 * hh; }
+
+// shifted softplus, kgcnn/ops/activ.py:15, in the form max(x,0) + log1p(exp(-|x|)) - log(2): identical to TF's
+// thresholded log1p(exp(x)) up to float rounding (|delta| < 2e-7 absolute) and free of overflow.
+__device__ __forceinline__ float ssp_fast(float x) {
+  const float t = __expf(-fabsf(x));
+  return fmaxf(x, 0.0f) + __logf(1.0f + t) - 0.6931471805599453f;
+}
+__device__ __forceinline__ float ssp_exact(float x) { return mp_softplus(x) - 0.6931471805599453f; }
+
+struct CfconvArgs {
+  const float* x;         // (N, F) sender-side node features
+  const float* edge_in;   // GAUSS: dist (M) ; else rbf (M, B)
+  const float* W1;        // (B, F)
+  const float* b1;        // (F) or null
+  const float* W2;        // (F, F)
+  const float* b2;        // (F) or null
+  const int32_t* recv;    // (M) receiver ids, ascending (already permuted if perm != null)
+  const int32_t* send;    // (M) sender ids in original edge order
+  const int32_t* perm;    // (M) sorted position -> original edge, or null
+  float* out;             // (N, F) zero-initialised
+  int64_t M, N;
+  int B;
+  float g_distance, g_gamma, g_offset;  // Gauss basis parameters (geom.py:567-571)
+  int ntiles;
+};
+
+template <int WAVES, bool GAUSS, bool FAST_SSP>
+__global__ __launch_bounds__(WAVES * 64) void cfconv_fused_kernel(CfconvArgs a) {
+  extern __shared__ __align__(16) float lds[];
+  float* W1s = lds;                          // [MAX_KROWS][F] packed
+  float* W2s = lds + MAX_KROWS * F;          // [F][F] packed
+  float* Ts = W2s + F * F;                   // [WAVES][F][T_LD]
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = tid >> 6;
+  const int c = lane & 31;
+  const int hh = lane >> 5;
+  const int B = a.B;
+  const int nk = (B + 2) >> 1;  // k-steps of GEMM1: B inputs + 1 bias row, two k per step
+
+  // ---- stage the weights once per workgroup: LDS[k][4*c + blk] = W[k][blk*32 + c] ---------------------------
+  for (int i = tid; i < 2 * nk * 32; i += WAVES * 64) {
+    const int k = i >> 5, cc = i & 31;
+    float4 v;
+    if (k < B) {
+      v = make_float4(a.W1[k * F + cc], a.W1[k * F + 32 + cc], a.W1[k * F + 64 + cc], a.W1[k * F + 96 + cc]);
+    } else if (k == B && a.b1) {
+      v = make_float4(a.b1[cc], a.b1[32 + cc], a.b1[64 + cc], a.b1[96 + cc]);
+    } else {
+      v = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    *reinterpret_cast<float4*>(W1s + k * F + 4 * cc) = v;
+  }
+  for (int i = tid; i < F * 32; i += WAVES * 64) {
+    const int k = i >> 5, cc = i & 31;
+    const float4 v = make_float4(a.W2[k * F + cc], a.W2[k * F + 32 + cc], a.W2[k * F + 64 + cc],
+                                 a.W2[k * F + 96 + cc]);
+    *reinterpret_cast<float4*>(W2s + k * F + 4 * cc) = v;
+  }
+  float bias2[4];
+#pragma unroll
+  for (int jb = 0; jb < 4; ++jb) bias2[jb] = a.b2 ? a.b2[jb * 32 + c] : 0.0f;
+  __syncthreads();
+
+  float* T = Ts + wave * (F * T_LD);
+  const float* w1_lane = W1s + (nk * hh) * F + 4 * c;  // + s*F           : rows s (lo half) / nk+s (hi half)
+  const float* w2_lane = W2s + (4 * hh) * F + 4 * c;   // + (ib*32 + (r&3) + 8*(r>>2))*F
+
+  for (int tile0 = blockIdx.x * WAVES + wave; tile0 < a.ntiles; tile0 += gridDim.x * WAVES) {
+    const int tile = __builtin_amdgcn_readfirstlane(tile0);
+    const int64_t e0 = static_cast<int64_t>(tile) * TE;
+    const int64_t e_mine = e0 + c;
+    const bool valid = e_mine < a.M;
+    const int64_t e_clamped = valid ? e_mine : a.M - 1;
+    const int64_t ep = a.perm ? static_cast<int64_t>(a.perm[e_clamped]) : e_clamped;
+    const int my_send = a.send[ep];
+
+    // ---- B operand of GEMM1: this lane's half of its edge's basis row (+ the constant 1 of the bias row) ----
+    float rb[MAX_KROWS / 2];
+    if constexpr (GAUSS) {
+      const float d = a.edge_in[ep];
+      const float fbins = static_cast<float>(B);
+#pragma unroll
+      for (int s = 0; s < MAX_KROWS / 2; ++s) {
+        const int k = s + nk * hh;
+        const float mu = static_cast<float>(k) / fbins * a.g_distance;
+        const float v = (d - a.g_offset) - mu;
+        float val = expf((v * v) * (a.g_gamma * -1.0f));
+        val = k < B ? val : (k == B ? 1.0f : 0.0f);
+        rb[s] = (s < nk && valid) ? val : 0.0f;
+      }
+    } else {
+#pragma unroll
+      for (int s = 0; s < MAX_KROWS / 2; ++s) {
+        const int k = s + nk * hh;
+        float val = 0.0f;
+        if (s < nk && valid) val = k < B ? a.edge_in[ep * B + k] : (k == B ? 1.0f : 0.0f);
+        rb[s] = val;
+      }
+    }
+
+    // ---- GEMM1 (transposed): hT[f][e] = sum_k W1p[k][f] * rb[e][k]; lane = edge, register = feature ---------
+    floatx16 h[4];
+#pragma unroll
+    for (int ib = 0; ib < 4; ++ib)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) h[ib][r] = 0.0f;
+#pragma unroll
+    for (int s = 0; s < MAX_KROWS / 2; ++s) {
+      if (s < nk) {
+        const float4 wv = *reinterpret_cast<const float4*>(w1_lane + s * F);
+        h[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(wv.x, rb[s], h[0], 0, 0, 0);
+        h[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(wv.y, rb[s], h[1], 0, 0, 0);
+        h[2] = __builtin_amdgcn_mfma_f32_32x32x2f32(wv.z, rb[s], h[2], 0, 0, 0);
+        h[3] = __builtin_amdgcn_mfma_f32_32x32x2f32(wv.w, rb[s], h[3], 0, 0, 0);
+      }
+    }
+#pragma unroll
+    for (int ib = 0; ib < 4; ++ib)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) h[ib][r] = FAST_SSP ? ssp_fast(h[ib][r]) : ssp_exact(h[ib][r]);
+
+    // ---- GEMM2: w[e][j] = sum_f h[e][f] W2[f][j] + b2[j]; A = the accumulator registers of GEMM1 ------------
+    floatx16 w[4];
+#pragma unroll
+    for (int jb = 0; jb < 4; ++jb)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) w[jb][r] = bias2[jb];
+#pragma unroll
+    for (int ib = 0; ib < 4; ++ib) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const float4 bv =
+            *reinterpret_cast<const float4*>(w2_lane + (ib * 32 + (r & 3) + 8 * (r >> 2)) * F);
+        const float av = h[ib][r];
+        w[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv.x, w[0], 0, 0, 0);
+        w[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv.y, w[1], 0, 0, 0);
+        w[2] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv.z, w[2], 0, 0, 0);
+        w[3] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv.w, w[3], 0, 0, 0);
+      }
+    }
+
+    // ---- multiply by the sender row (coalesced 128-B reads) and transpose into the slab [feature][edge] -------
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      float4 m[4];
+      float* mp = reinterpret_cast<float*>(m);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int r = q * 4 + i;
+        const int row = rowmap(r, hh);
+        const int snode = __shfl(my_send, row, 64);
+        const bool row_valid = (e0 + row) < a.M;
+        const float* xrow = a.x + static_cast<int64_t>(snode) * F + c;
+#pragma unroll
+        for (int jb = 0; jb < 4; ++jb) {
+          const float xv = row_valid ? xrow[jb * 32] : 0.0f;
+          mp[jb * 4 + i] = w[jb][r] * xv;
+        }
+      }
+#pragma unroll
+      for (int jb = 0; jb < 4; ++jb)
+        *reinterpret_cast<float4*>(T + (jb * 32 + c) * T_LD + 8 * q + 4 * hh) = m[jb];
+    }
+    // the slab is private to this wave: LDS operations of one wave complete in order, no barrier needed
+    float va[TE], vb[TE];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+      const float4 ta = *reinterpret_cast<const float4*>(T + lane * T_LD + 4 * q);
+      const float4 tb = *reinterpret_cast<const float4*>(T + (64 + lane) * T_LD + 4 * q);
+      va[4 * q] = ta.x; va[4 * q + 1] = ta.y; va[4 * q + 2] = ta.z; va[4 * q + 3] = ta.w;
+      vb[4 * q] = tb.x; vb[4 * q + 1] = tb.y; vb[4 * q + 2] = tb.z; vb[4 * q + 3] = tb.w;
+    }
+
+    // ---- in-order segmented sum over the 32 edges; receiver ids are wave-uniform --------------------------
+    const int64_t last = a.M - 1;
+    int cur = a.recv[e0];
+    float sa = va[0], sb = vb[0];
+    bool first = true;
+#pragma unroll
+    for (int i = 1; i < TE; ++i) {
+      const int64_t ei = (e0 + i) <= last ? (e0 + i) : last;  // padding edges carry zeros into the last segment
+      const int ri = a.recv[ei];
+      if (ri != cur) {
+        float* dst = a.out + static_cast<int64_t>(cur) * F + lane;
+        if (first) {
+          atomicAdd(dst, sa);
+          atomicAdd(dst + 64, sb);
+          first = false;
+        } else {
+          dst[0] = sa;
+          dst[64] = sb;
+        }
+        cur = ri;
+        sa = va[i];
+        sb = vb[i];
+      } else {
+        sa += va[i];
+        sb += vb[i];
+      }
+    }
+    float* dst = a.out + static_cast<int64_t>(cur) * F + lane;
+    atomicAdd(dst, sa);
+    atomicAdd(dst + 64, sb);
+  }
+}
+
+template <int WAVES>
+size_t cfconv_lds_bytes() {
+  return sizeof(float) * (MAX_KROWS * F + F * F + WAVES * F * T_LD);
+}
+
+template <int WAVES, bool GAUSS, bool FAST>
+int launch_cfconv(const CfconvArgs& args, int grid, hipStream_t s) {
+  const size_t lds = cfconv_lds_bytes<WAVES>();
+  static bool attr_set = false;
+  if (!attr_set) {
+    MP_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&cfconv_fused_kernel<WAVES, GAUSS, FAST>),
+                               hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds)));
+    attr_set = true;
+  }
+  cfconv_fused_kernel<WAVES, GAUSS, FAST><<<grid, WAVES * 64, lds, s>>>(args);
+  return mp::check_launch("mp_cfconv_fused_f32");
+}
+
+int cfconv_dispatch(CfconvArgs args, bool gauss, int flags, hipStream_t s) {
+  MP_REQUIRE(args.M >= 0 && args.N >= 0, "mp_cfconv: bad sizes");
+  MP_REQUIRE(args.B >= 1 && args.B <= MAX_KROWS - 2, "mp_cfconv: basis size B=%d must be in 1..%d", args.B,
+             MAX_KROWS - 2);
+  if (args.M == 0 || args.N == 0) return MP_OK;
+  MP_REQUIRE(args.x && args.edge_in && args.W1 && args.W2 && args.recv && args.send && args.out,
+             "mp_cfconv: null pointer");
+  MP_REQUIRE(args.M < (int64_t{1} << 31), "mp_cfconv: M must fit int32");
+  args.ntiles = static_cast<int>((args.M + TE - 1) / TE);
+  const bool fast = (flags & 1) != 0;
+  // one workgroup per CU (LDS holds the weights); persistent over the tiles
+  int grid = (args.ntiles + 3) / 4;
+  if (grid > 256) grid = 256;
+  if (gauss) {
+    return fast ? launch_cfconv<4, true, true>(args, grid, s) : launch_cfconv<4, true, false>(args, grid, s);
+  }
+  return fast ? launch_cfconv<4, false, true>(args, grid, s) : launch_cfconv<4, false, false>(args, grid, s);
+}
+
+}  // namespace
+
+extern "C" {
+
+int mp_cfconv_fused_f32(const float* x, int64_t N, const float* rbf, int B, const float* W1, const float* b1,
+                        const float* W2, const float* b2, const int32_t* recv_sorted, const int32_t* send,
+                        const int32_t* perm, int64_t M, int flags, float* out_zeroed, mpStream_t stream) {
+  CfconvArgs a{};
+  a.x = x; a.edge_in = rbf; a.W1 = W1; a.b1 = b1; a.W2 = W2; a.b2 = b2;
+  a.recv = recv_sorted; a.send = send; a.perm = perm; a.out = out_zeroed;
+  a.M = M; a.N = N; a.B = B;
+  return cfconv_dispatch(a, false, flags, mp::as_stream(stream));
+}
+
+int mp_cfconv_gauss_fused_f32(const float* x, int64_t N, const float* dist, int bins, float distance, float sigma,
+                              float offset, const float* W1, const float* b1, const float* W2, const float* b2,
+                              const int32_t* recv_sorted, const int32_t* send, const int32_t* perm, int64_t M,
+                              int flags, float* out_zeroed, mpStream_t stream) {
+  MP_REQUIRE(sigma != 0.0f, "mp_cfconv_gauss_fused_f32: sigma must be non-zero");
+  CfconvArgs a{};
+  a.x = x; a.edge_in = dist; a.W1 = W1; a.b1 = b1; a.W2 = W2; a.b2 = b2;
+  a.recv = recv_sorted; a.send = send; a.perm = perm; a.out = out_zeroed;
+  a.M = M; a.N = N; a.B = bins;
+  a.g_distance = distance;
+  a.g_gamma = static_cast<float>(1.0 / static_cast<double>(sigma) / static_cast<double>(sigma) / 2.0);
+  a.g_offset = offset;
+  return cfconv_dispatch(a, true, flags, mp::as_stream(stream));
+}
+
+}  // extern "C"

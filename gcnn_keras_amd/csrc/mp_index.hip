@@ -83,6 +83,48 @@ __global__ void csr_from_sorted_kernel(const int32_t* __restrict__ seg, int64_t 
   }
 }
 
+// index_prepare (K = 2) fused with the geometry pre-step NodePosition -> LazySubtract -> EuclideanNorm
+// (kgcnn/literature/Schnet.py:116-117): one pass over the (M,2) int64 rows yields receiver / sender ids and the
+// edge distance the Gauss expansion starts from.
+__global__ void edge_prepare_kernel(const int64_t* __restrict__ idx, int64_t M, const int64_t* __restrict__ node_splits,
+                                    const int64_t* __restrict__ edge_splits, int64_t G, int64_t N,
+                                    const float* __restrict__ xyz, int32_t* __restrict__ recv,
+                                    int32_t* __restrict__ send, float* __restrict__ dist,
+                                    int32_t* __restrict__ flags) {
+  const int64_t stride = static_cast<int64_t>(gridDim.x) * blockDim.x;
+  int local_flags = 0;
+  for (int64_t e = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x; e < M; e += stride) {
+    const int64_t g = owner_of(edge_splits, G, e);
+    const int64_t base = node_splits[g];
+    const int64_t n_g = node_splits[g + 1] - base;
+    const longlong2 v = reinterpret_cast<const longlong2*>(idx)[e];
+    int64_t i = v.x, j = v.y;
+    if (i < 0 || i >= n_g || j < 0 || j >= n_g) {
+      local_flags |= MP_FLAG_OOB;
+      const int64_t hi = n_g > 0 ? n_g - 1 : 0;
+      i = i < 0 ? 0 : (i > hi ? hi : i);
+      j = j < 0 ? 0 : (j > hi ? hi : j);
+    }
+    int64_t si = i + base, sj = j + base;
+    if (si >= N) si = N > 0 ? N - 1 : 0;
+    if (sj >= N) sj = N > 0 ? N - 1 : 0;
+    recv[e] = static_cast<int32_t>(si);
+    send[e] = static_cast<int32_t>(sj);
+    if (e > 0) {
+      int64_t base_prev = base;
+      if (edge_splits[g] > e - 1) base_prev = node_splits[owner_of(edge_splits, G, e - 1)];
+      if (idx[(e - 1) * 2] + base_prev > si) local_flags |= MP_FLAG_UNSORTED_COL0;
+    }
+    if (dist) {
+      const float dx = xyz[si * 3 + 0] - xyz[sj * 3 + 0];
+      const float dy = xyz[si * 3 + 1] - xyz[sj * 3 + 1];
+      const float dz = xyz[si * 3 + 2] - xyz[sj * 3 + 2];
+      dist[e] = sqrtf(fmaxf(dx * dx + dy * dy + dz * dz, 0.0f));
+    }
+  }
+  if (local_flags) atomicOr(flags, local_flags);
+}
+
 __global__ void iota_kernel(int32_t* __restrict__ out, int64_t n) {
   const int64_t stride = static_cast<int64_t>(gridDim.x) * blockDim.x;
   for (int64_t i = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x; i < n; i += stride)
@@ -117,6 +159,20 @@ int mp_index_prepare_i64(const int64_t* idx, int64_t M, int K, const int64_t* no
   index_prepare_kernel<<<mp::grid_for(M), 256, 0, mp::as_stream(stream)>>>(idx, M, K, node_splits, edge_splits, G, N,
                                                                             cols, flags);
   return mp::check_launch("mp_index_prepare_i64");
+}
+
+int mp_edge_prepare_i64_f32(const int64_t* idx, int64_t M, const int64_t* node_splits, const int64_t* edge_splits,
+                            int64_t G, int64_t N, const float* xyz, int32_t* recv, int32_t* send, float* dist,
+                            int32_t* flags, mpStream_t stream) {
+  MP_REQUIRE(M >= 0 && G >= 0 && N >= 0, "mp_edge_prepare_i64_f32: bad sizes");
+  MP_REQUIRE(N < (int64_t{1} << 31) && M < (int64_t{1} << 31), "mp_edge_prepare_i64_f32: N, M must fit int32");
+  MP_REQUIRE(flags != nullptr, "mp_edge_prepare_i64_f32: null flags");
+  MP_REQUIRE((dist == nullptr) || (xyz != nullptr), "mp_edge_prepare_i64_f32: dist requested without coordinates");
+  if (M == 0) return MP_OK;
+  MP_REQUIRE(idx && recv && send && node_splits && edge_splits && G > 0, "mp_edge_prepare_i64_f32: null pointer");
+  edge_prepare_kernel<<<mp::grid_for(M), 256, 0, mp::as_stream(stream)>>>(idx, M, node_splits, edge_splits, G, N, xyz,
+                                                                           recv, send, dist, flags);
+  return mp::check_launch("mp_edge_prepare_i64_f32");
 }
 
 int mp_csr_from_sorted_i32(const int32_t* seg, int64_t M, int64_t N, int32_t* ptr, mpStream_t stream) {

@@ -1,0 +1,303 @@
+// Node-side chains of the SchNet forward (kgcnn/literature/Schnet.py:110-133, schnet_conv.py:159-165), fused per
+// 16-node tile so that no intermediate (N,F) activation makes a round trip through HBM:
+//
+//   IN   : n = Dense(F, linear)(Embedding(Z))            Schnet.py:110-111,125      x = Dense_nobias(n)   conv:160
+//   MID  : y = Dense(lin)(Dense(ssp)(agg)) ; n += y      schnet_conv.py:162-164     x = Dense_nobias(n)   (next block)
+//   LAST : y = ...; n += y ; h = MLP([F, 64], ssp)(n)    Schnet.py:129  (last_mlp)  -> (N, 64)
+//   readout: PoolingNodes(sum) + MLP([64, 1])            Schnet.py:133-135
+//
+// These chains are latency bound at QM9 batch sizes (2301 nodes = 144 tiles of 16): four waves of a workgroup
+// cooperate on one tile, each wave producing a 32-column slice of every GEMM with v_mfma_f32_16x16x4_f32 (two
+// independent 16x16 accumulators per wave cover its 40-cycle dependent latency).  The wave keeps its slice of
+// every weight matrix in REGISTERS for the life of the persistent workgroup (64 VGPRs per 128x32 slice, loaded
+// once with coalesced 64-B reads), so the only LDS traffic is the 16x128 activation tile handed from one GEMM to
+// the next.  The MID / LAST kernels also re-zero the aggregation rows they consumed, so the next cfconv launch
+// needs no memset.
+#include "mp_common.h"
+
+namespace {
+
+using floatx4 = __attribute__((ext_vector_type(4))) float;
+
+constexpr int F = 128;
+constexpr int TN = 16;     // nodes per tile
+constexpr int X_LD = 130;  // padded row stride of the LDS activation tiles: (2*node + k) mod 32 is conflict-free
+
+__device__ __forceinline__ float ssp_exact(float x) { return mp_softplus(x) - 0.6931471805599453f; }
+
+// Slice of W (K x U, row-major) for output columns col0 + 16*cb + (lane&15), k = 4*s + (lane>>4).
+template <int K, int NCB>
+__device__ __forceinline__ void load_wslice(const float* __restrict__ W, int U, int col0, int lane,
+                                            float (&wr)[NCB][K / 4]) {
+  const int g = lane >> 4, cc = lane & 15;
+#pragma unroll
+  for (int cb = 0; cb < NCB; ++cb)
+#pragma unroll
+    for (int s = 0; s < K / 4; ++s) wr[cb][s] = W[(4 * s + g) * U + col0 + 16 * cb + cc];
+}
+
+// acc[cb] += Xs(16 x K) @ Wslice ; A operand from LDS: lane supplies Xs[node = lane&15][k = 4s + (lane>>4)].
+template <int K, int NCB>
+__device__ __forceinline__ void gemm_tile(const float* __restrict__ Xs, int lane, const float (&wr)[NCB][K / 4],
+                                          floatx4 (&acc)[NCB]) {
+  const float* xp = Xs + (lane & 15) * X_LD + (lane >> 4);
+#pragma unroll
+  for (int s = 0; s < K / 4; ++s) {
+    const float av = xp[4 * s];
+#pragma unroll
+    for (int cb = 0; cb < NCB; ++cb) acc[cb] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, wr[cb][s], acc[cb], 0, 0, 0);
+  }
+}
+
+struct NodeArgs {
+  int64_t N;
+  int ntiles;
+  // IN
+  const float* numbers;  // (N) float node numbers
+  const float* emb;      // (vocab, E)
+  int vocab;
+  const float* W0;       // (E, F)
+  const float* b0;       // (F)
+  // MID / LAST
+  float* agg;            // (N, F) aggregated messages, re-zeroed on exit
+  const float* W2;       // (F, F) interaction dense2 (ssp)
+  const float* b2;
+  const float* W3;       // (F, F) interaction dense3 (linear)
+  const float* b3;
+  // all
+  float* n;              // (N, F) node state (IN: written; MID/LAST: updated in place)
+  const float* Wx;       // (F, F) next block's dense1 (no bias)          [IN, MID]
+  float* x;              // (N, F) next block's sender features           [IN, MID]
+  // LAST
+  const float* Wl0;      // (F, F) last_mlp[0] (ssp)
+  const float* bl0;
+  const float* Wl1;      // (F, 64) last_mlp[1] (ssp)
+  const float* bl1;
+  float* h;              // (N, 64)
+};
+
+enum NodeMode { NODE_IN = 0, NODE_MID = 1, NODE_LAST = 2 };
+
+// Epilogue helper: visit the wave's output elements.  C layout of 16x16x4: col = lane&15, row = 4*(lane>>4) + r.
+#define MP_FOR_OUT(cb, r, row, col, body)                           \
+  _Pragma("unroll") for (int cb = 0; cb < 2; ++cb) {                \
+    _Pragma("unroll") for (int r = 0; r < 4; ++r) {                 \
+      const int row = 4 * (lane >> 4) + r;                          \
+      const int col = wave * 32 + 16 * cb + (lane & 15);            \
+      body                                                          \
+    }                                                               \
+  }
+
+template <int MODE, int E>
+__global__ __launch_bounds__(256) void schnet_node_kernel(NodeArgs a) {
+  __shared__ float Xa[TN * X_LD];
+  __shared__ float Xb[TN * X_LD];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = tid >> 6;
+
+  // ---- weight slices -> registers (once per persistent workgroup) -------------------------------------------
+  float w_first[2][(MODE == NODE_IN ? E : F) / 4];   // IN: W0 ; MID/LAST: W2
+  float w_second[2][F / 4];                          // IN: Wx ; MID/LAST: W3
+  float w_third[2][(MODE == NODE_IN ? 4 : F) / 4];   // MID: Wx ; LAST: Wl0
+  float w_fourth[1][(MODE == NODE_LAST ? F : 4) / 4];  // LAST: Wl1 (16 columns per wave)
+  float bias_first[2], bias_second[2], bias_third[2], bias_fourth;
+  if constexpr (MODE == NODE_IN) {
+    load_wslice<E, 2>(a.W0, F, wave * 32, lane, w_first);
+    load_wslice<F, 2>(a.Wx, F, wave * 32, lane, w_second);
+  } else {
+    load_wslice<F, 2>(a.W2, F, wave * 32, lane, w_first);
+    load_wslice<F, 2>(a.W3, F, wave * 32, lane, w_second);
+    if constexpr (MODE == NODE_MID) load_wslice<F, 2>(a.Wx, F, wave * 32, lane, w_third);
+    if constexpr (MODE == NODE_LAST) {
+      load_wslice<F, 2>(a.Wl0, F, wave * 32, lane, w_third);
+      load_wslice<F, 1>(a.Wl1, 64, wave * 16, lane, w_fourth);
+    }
+  }
+#pragma unroll
+  for (int cb = 0; cb < 2; ++cb) {
+    const int col = wave * 32 + 16 * cb + (lane & 15);
+    if constexpr (MODE == NODE_IN) {
+      bias_first[cb] = a.b0 ? a.b0[col] : 0.0f;
+      bias_second[cb] = 0.0f;
+      bias_third[cb] = 0.0f;
+    } else {
+      bias_first[cb] = a.b2 ? a.b2[col] : 0.0f;
+      bias_second[cb] = a.b3 ? a.b3[col] : 0.0f;
+      bias_third[cb] = (MODE == NODE_LAST && a.bl0) ? a.bl0[col] : 0.0f;
+    }
+  }
+  bias_fourth = (MODE == NODE_LAST && a.bl1) ? a.bl1[wave * 16 + (lane & 15)] : 0.0f;
+
+  for (int tile = blockIdx.x; tile < a.ntiles; tile += gridDim.x) {
+    const int64_t node0 = static_cast<int64_t>(tile) * TN;
+
+    // ---- stage the input tile into Xa (coalesced), re-zero the consumed aggregation rows ---------------------
+    if constexpr (MODE == NODE_IN) {
+      for (int i = tid; i < TN * E; i += 256) {
+        const int r = i / E, k = i % E;
+        const int64_t node = node0 + r;
+        float v = 0.0f;
+        if (node < a.N) {
+          const int z = static_cast<int>(a.numbers[node]);  // Keras Embedding casts float input to int32
+          if (z >= 0 && z < a.vocab) v = a.emb[static_cast<int64_t>(z) * E + k];
+        }
+        Xa[r * X_LD + k] = v;
+      }
+    } else {
+      for (int i = tid; i < TN * F / 4; i += 256) {
+        const int r = i / (F / 4), k4 = i % (F / 4);
+        const int64_t node = node0 + r;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (node < a.N) {
+          float4* p = reinterpret_cast<float4*>(a.agg + node * F) + k4;
+          v = *p;
+          *p = make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+        float* d = Xa + r * X_LD + 4 * k4;
+        d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
+      }
+    }
+    __syncthreads();
+
+    floatx4 acc[2];
+    // ---- GEMM 1: IN: n = emb @ W0 + b0 ; MID/LAST: t = ssp(agg @ W2 + b2) ---------------------------------------
+#pragma unroll
+    for (int cb = 0; cb < 2; ++cb) acc[cb] = floatx4{0.f, 0.f, 0.f, 0.f};
+    gemm_tile<(MODE == NODE_IN ? E : F), 2>(Xa, lane, w_first, acc);
+    MP_FOR_OUT(cb, r, row, col, {
+      float v = acc[cb][r] + bias_first[cb];
+      if constexpr (MODE != NODE_IN) v = ssp_exact(v);
+      Xb[row * X_LD + col] = v;
+      if constexpr (MODE == NODE_IN) {
+        if (node0 + row < a.N) a.n[(node0 + row) * F + col] = v;
+      }
+    })
+    __syncthreads();
+
+    // ---- GEMM 2: IN: x = n @ Wx ; MID/LAST: n += t @ W3 + b3 ----------------------------------------------------
+#pragma unroll
+    for (int cb = 0; cb < 2; ++cb) acc[cb] = floatx4{0.f, 0.f, 0.f, 0.f};
+    gemm_tile<F, 2>(Xb, lane, w_second, acc);
+    if constexpr (MODE == NODE_IN) {
+      MP_FOR_OUT(cb, r, row, col, {
+        if (node0 + row < a.N) a.x[(node0 + row) * F + col] = acc[cb][r];
+      })
+    } else {
+      MP_FOR_OUT(cb, r, row, col, {
+        const bool ok = node0 + row < a.N;
+        const float y = acc[cb][r] + bias_second[cb];
+        const float nv = ok ? a.n[(node0 + row) * F + col] : 0.0f;
+        const float nn = nv + y;  // LazyAdd([node, x])
+        if (ok && MODE == NODE_MID) a.n[(node0 + row) * F + col] = nn;
+        Xa[row * X_LD + col] = nn;
+      })
+      __syncthreads();
+
+      // ---- GEMM 3: MID: x = n @ Wx ; LAST: u = ssp(n @ Wl0 + bl0) ----------------------------------------------
+#pragma unroll
+      for (int cb = 0; cb < 2; ++cb) acc[cb] = floatx4{0.f, 0.f, 0.f, 0.f};
+      gemm_tile<F, 2>(Xa, lane, w_third, acc);
+      if constexpr (MODE == NODE_MID) {
+        MP_FOR_OUT(cb, r, row, col, {
+          if (node0 + row < a.N) a.x[(node0 + row) * F + col] = acc[cb][r];
+        })
+      } else {
+        MP_FOR_OUT(cb, r, row, col, { Xb[row * X_LD + col] = ssp_exact(acc[cb][r] + bias_third[cb]); })
+        __syncthreads();
+        // ---- GEMM 4 (LAST): h = ssp(u @ Wl1 + bl1), 64 output columns = 16 per wave ------------------------------
+        floatx4 acc4[1];
+        acc4[0] = floatx4{0.f, 0.f, 0.f, 0.f};
+        gemm_tile<F, 1>(Xb, lane, w_fourth, acc4);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int row = 4 * (lane >> 4) + r;
+          const int col = wave * 16 + (lane & 15);
+          if (node0 + row < a.N) a.h[(node0 + row) * 64 + col] = ssp_exact(acc4[0][r] + bias_fourth);
+        }
+      }
+    }
+    __syncthreads();  // Xa / Xb are reused by the next tile
+  }
+}
+
+// Readout: PoolingNodes(sum) over each graph's rows of h (N,64), then MLP([64,1], [ssp, linear]).
+// One wave per graph, lane = feature; sequential node order (the order tf.math.segment_sum uses).
+__global__ void schnet_readout_kernel(const float* __restrict__ h, const int64_t* __restrict__ splits, int64_t G,
+                                      const float* __restrict__ Wo0, const float* __restrict__ bo0,
+                                      const float* __restrict__ Wo1, const float* __restrict__ bo1,
+                                      float* __restrict__ out) {
+  const int lane = threadIdx.x & 63;
+  const int64_t wave_global = (static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x) >> 6;
+  const int64_t nwaves = (static_cast<int64_t>(gridDim.x) * blockDim.x) >> 6;
+  for (int64_t g = wave_global; g < G; g += nwaves) {
+    float pooled = 0.0f;
+    for (int64_t nidx = splits[g]; nidx < splits[g + 1]; ++nidx) pooled += h[nidx * 64 + lane];
+    float y = 0.0f;
+#pragma unroll 8
+    for (int k = 0; k < 64; ++k) y = fmaf(__shfl(pooled, k, 64), Wo0[k * 64 + lane], y);
+    y = ssp_exact(y + (bo0 ? bo0[lane] : 0.0f));
+    float o = y * Wo1[lane];
+    for (int off = 32; off > 0; off >>= 1) o += __shfl_xor(o, off, 64);
+    if (lane == 0) out[g] = o + (bo1 ? bo1[0] : 0.0f);
+  }
+}
+
+template <int MODE, int E>
+int launch_node(const NodeArgs& a, hipStream_t s, const char* what) {
+  int grid = a.ntiles < 256 ? a.ntiles : 256;
+  schnet_node_kernel<MODE, E><<<grid, 256, 0, s>>>(a);
+  return mp::check_launch(what);
+}
+
+}  // namespace
+
+extern "C" {
+
+int mp_schnet_node_in_f32(const float* numbers, int64_t N, const float* emb, int vocab, int emb_dim, const float* W0,
+                          const float* b0, const float* Wx, float* n_out, float* x_out, mpStream_t stream) {
+  MP_REQUIRE(N >= 0 && vocab >= 1, "mp_schnet_node_in_f32: bad sizes");
+  MP_REQUIRE(emb_dim == 64, "mp_schnet_node_in_f32: built for embedding width 64 (got %d)", emb_dim);
+  if (N == 0) return MP_OK;
+  MP_REQUIRE(numbers && emb && W0 && Wx && n_out && x_out, "mp_schnet_node_in_f32: null pointer");
+  NodeArgs a{};
+  a.N = N; a.ntiles = static_cast<int>((N + TN - 1) / TN);
+  a.numbers = numbers; a.emb = emb; a.vocab = vocab; a.W0 = W0; a.b0 = b0; a.Wx = Wx; a.n = n_out; a.x = x_out;
+  return launch_node<NODE_IN, 64>(a, mp::as_stream(stream), "mp_schnet_node_in_f32");
+}
+
+int mp_schnet_node_update_f32(float* agg, int64_t N, const float* W2, const float* b2, const float* W3,
+                              const float* b3, float* n_inout, const float* Wx_next, float* x_out, mpStream_t stream) {
+  MP_REQUIRE(N >= 0, "mp_schnet_node_update_f32: bad sizes");
+  if (N == 0) return MP_OK;
+  MP_REQUIRE(agg && W2 && W3 && n_inout && Wx_next && x_out, "mp_schnet_node_update_f32: null pointer");
+  NodeArgs a{};
+  a.N = N; a.ntiles = static_cast<int>((N + TN - 1) / TN);
+  a.agg = agg; a.W2 = W2; a.b2 = b2; a.W3 = W3; a.b3 = b3; a.n = n_inout; a.Wx = Wx_next; a.x = x_out;
+  return launch_node<NODE_MID, 64>(a, mp::as_stream(stream), "mp_schnet_node_update_f32");
+}
+
+int mp_schnet_node_last_f32(float* agg, int64_t N, const float* W2, const float* b2, const float* W3, const float* b3,
+                            const float* n_in, const float* Wl0, const float* bl0, const float* Wl1, const float* bl1,
+                            float* h_out, mpStream_t stream) {
+  MP_REQUIRE(N >= 0, "mp_schnet_node_last_f32: bad sizes");
+  if (N == 0) return MP_OK;
+  MP_REQUIRE(agg && W2 && W3 && n_in && Wl0 && Wl1 && h_out, "mp_schnet_node_last_f32: null pointer");
+  NodeArgs a{};
+  a.N = N; a.ntiles = static_cast<int>((N + TN - 1) / TN);
+  a.agg = agg; a.W2 = W2; a.b2 = b2; a.W3 = W3; a.b3 = b3; a.n = const_cast<float*>(n_in);
+  a.Wl0 = Wl0; a.bl0 = bl0; a.Wl1 = Wl1; a.bl1 = bl1; a.h = h_out;
+  return launch_node<NODE_LAST, 64>(a, mp::as_stream(stream), "mp_schnet_node_last_f32");
+}
+
+int mp_schnet_readout_f32(const float* h, const int64_t* node_splits, int64_t G, const float* Wo0, const float* bo0,
+                          const float* Wo1, const float* bo1, float* out, mpStream_t stream) {
+  MP_REQUIRE(G >= 0, "mp_schnet_readout_f32: bad sizes");
+  if (G == 0) return MP_OK;
+  MP_REQUIRE(h && node_splits && Wo0 && Wo1 && out, "mp_schnet_readout_f32: null pointer");
+  schnet_readout_kernel<<<mp::grid_for(G * 64), 256, 0, mp::as_stream(stream)>>>(h, node_splits, G, Wo0, bo0, Wo1,
+                                                                                  bo1, out);
+  return mp::check_launch("mp_schnet_readout_f32");
+}
+
+}  // extern "C"

@@ -1,0 +1,141 @@
+"""Whole-forward drivers of the SchNet hot path (kgcnn/literature/Schnet.py:104-148) on one GPU.
+
+``SchnetForward`` owns a resident batch and runs one forward per ``forward()`` call in one of two modes:
+
+* ``layers``: the reference's layer graph, one engine primitive per Keras layer (gcnn_keras_amd.layers.*).
+* ``fused``:  the same arithmetic in a handful of fused kernels replayed from a HIP graph (csrc/mp_schnet_*.hip).
+
+Both go through the C ABI only; there is no CPU path.
+"""
+import ctypes
+
+import numpy as np
+import torch
+
+from . import _ffi
+from .ragged import RaggedTensor
+
+
+class _HipTimer:
+    """HIP events on torch's current stream via the C ABI (``torch.cuda.Event`` would also see only that stream)."""
+
+    def __init__(self):
+        self.start, self.stop = ctypes.c_void_p(), ctypes.c_void_p()
+        _ffi.call("mp_event_create", ctypes.byref(self.start))
+        _ffi.call("mp_event_create", ctypes.byref(self.stop))
+
+    def time_ms(self, fn, iters):
+        fn()
+        torch.cuda.synchronize()
+        _ffi.call("mp_event_record", self.start, _ffi.stream())
+        for _ in range(iters):
+            fn()
+        _ffi.call("mp_event_record", self.stop, _ffi.stream())
+        ms = ctypes.c_float(0.0)
+        _ffi.call("mp_event_elapsed_ms", self.start, self.stop, ctypes.byref(ms))
+        return ms.value / iters
+
+    def __del__(self):
+        try:
+            _ffi.call("mp_event_destroy", self.start)
+            _ffi.call("mp_event_destroy", self.stop)
+        except Exception:
+            pass
+
+
+class SchnetForward:
+    def __init__(self, params, depth=3, mode="auto", units=128, bins=20, gauss_args=None):
+        from .literature import Schnet
+        if not torch.cuda.is_available():
+            raise _ffi.EngineError("SchnetForward needs an MI355X (no CPU fallback)")
+        self.params = params
+        self.depth = depth
+        self.units = units
+        self.gauss_args = gauss_args or {"bins": bins, "distance": 4, "offset": 0.0, "sigma": 0.4}
+        if mode == "auto":
+            mode = "fused" if _fused_available() else "layers"
+        self.mode = mode
+        self.num_launches = None
+        self.model = Schnet.make_model(depth=depth, gauss_args=self.gauss_args)
+        self.model.set_weights(list(params.values()))
+        self._batch = None
+        self._fused = None
+        if mode == "fused":
+            from .fused import FusedSchnet
+            self._fused = FusedSchnet(params, depth=depth, gauss_args=self.gauss_args)
+
+    # ------------------------------------------------------------------------------------------------ batch
+    def load_batch(self, batch):
+        """Host arrays -> HBM (outside the timed region: inputs are resident when the clock starts)."""
+        dev = "cuda"
+        self._batch = {
+            "z": torch.from_numpy(batch["node_number"]).to(dev),
+            "xyz": torch.from_numpy(batch["node_coordinates"]).to(dev),
+            "idx": torch.from_numpy(batch["edge_indices"]).to(dev),
+            "ns": torch.from_numpy(batch["node_splits"]).to(dev),
+            "es": torch.from_numpy(batch["edge_splits"]).to(dev),
+            "ns_host": batch["node_splits"], "es_host": batch["edge_splits"],
+        }
+        self.N = int(batch["node_splits"][-1])
+        self.M = int(batch["edge_splits"][-1])
+        self.G = len(batch["node_splits"]) - 1
+        if self._fused is not None:
+            self._fused.bind(self._batch, self.N, self.M, self.G)
+        torch.cuda.synchronize()
+
+    def _fresh_inputs(self):
+        """New ragged wrappers every step, so nothing cached on them (index plan, CSR) leaks across steps."""
+        b = self._batch
+
+        def rag(v, s, sh):
+            r = RaggedTensor(v, s)
+            r._splits_host = sh  # partition sizes are batch metadata from the host-side loader
+            return r
+
+        return [rag(b["z"], b["ns"], b["ns_host"]), rag(b["xyz"], b["ns"], b["ns_host"]),
+                rag(b["idx"], b["es"], b["es_host"])]
+
+    # ------------------------------------------------------------------------------------------------ forward
+    def forward(self):
+        if self._fused is not None:
+            return self._fused.forward()
+        before = _ffi.launch_count()
+        out = self.model(self._fresh_inputs())
+        self.num_launches = _ffi.launch_count() - before
+        return out
+
+    def check_flags(self):
+        if self._fused is not None:
+            self._fused.check_flags()
+
+    # ------------------------------------------------------------------------------------------------ roofline
+    def roofline(self, hbm_peak_gbs, mfma_peak_tf, iters=50):
+        """Dominant kernel of the forward, timed live with HIP events on the stream it is launched on."""
+        if self._fused is not None:
+            self.num_launches = self._fused.num_launches
+            return self._fused.roofline(hbm_peak_gbs, mfma_peak_tf, iters)
+        # layers mode: the per-edge filter GEMM (M,128)x(128,128) of SchNetCFconv.lay_dense2 dominates
+        m, f = self.M, self.units
+        x = torch.randn(m, f, device="cuda")
+        w = torch.randn(f, f, device="cuda") * 0.1
+        b = torch.zeros(f, device="cuda")
+        out = torch.empty(m, f, device="cuda")
+
+        def launch():
+            _ffi.call("mp_dense_f32", _ffi.ptr(x), m, f, _ffi.ptr(w), _ffi.ptr(b), f, 0, 0.0, _ffi.ptr(out),
+                      _ffi.stream())
+
+        ms = _HipTimer().time_ms(launch, iters)
+        flops = 2.0 * m * f * f
+        achieved = flops / (ms * 1e-3) / 1e12
+        return {"bound": "mfma", "kernel": "dense_mfma_kernel (edge filter GEMM (M,128)x(128,128))",
+                "achieved": achieved, "peak": mfma_peak_tf, "unit": "TFLOP/s", "frac": achieved / mfma_peak_tf,
+                "traffic": None, "avg_launch_us": ms * 1e3, "algorithmic_flops_per_launch": flops}
+
+
+def _fused_available():
+    try:
+        lib = _ffi.lib()
+        return hasattr(lib, "mp_schnet_cfconv_fused_f32")
+    except Exception:
+        return False

@@ -176,6 +176,42 @@ int mp_edge_geometry_f32(const float* xyz, int64_t N, const int32_t* recv, const
 int mp_ragged_to_padded_f32(const float* values, const int64_t* row_splits, int64_t G, int64_t Nmax, int64_t row_elems,
                             float* padded, float* mask, mpStream_t stream);
 
+/* ---------------------------------------------------------------- fused SchNet path --------------------- */
+/* mp_index_prepare_i64 for K = 2 fused with NodePosition -> LazySubtract -> EuclideanNorm
+ * (kgcnn/literature/Schnet.py:116-117): recv (M), send (M) shifted int32 ids, dist (M) nullable = ||x_i - x_j||,
+ * flags as mp_index_prepare_i64 (column 0 sortedness only). */
+int mp_edge_prepare_i64_f32(const int64_t* idx, int64_t M, const int64_t* node_splits, const int64_t* edge_splits,
+                            int64_t G, int64_t N, const float* xyz, int32_t* recv, int32_t* send, float* dist,
+                            int32_t* flags, mpStream_t stream);
+
+/* SchNetCFconv.call, kgcnn/layers/conv/schnet_conv.py:73-79, fused (F = units = 128, cfconv_pool = sum,
+ * activation = shifted_softplus): out[i] += sum_{e: recv[e]=i} x[send[e]] * (ssp(rbf[e] W1 + b1) W2 + b2).
+ * recv_sorted ascending; perm (nullable) maps sorted position -> original edge (rbf / send are in original
+ * order); out (N,128) must be zero on entry.  flags bit0: fast softplus (v_exp/v_log form, |delta| < 2e-7). */
+int mp_cfconv_fused_f32(const float* x, int64_t N, const float* rbf, int B, const float* W1, const float* b1,
+                        const float* W2, const float* b2, const int32_t* recv_sorted, const int32_t* send,
+                        const int32_t* perm, int64_t M, int flags, float* out_zeroed, mpStream_t stream);
+/* Same with GaussBasisLayer (kgcnn/layers/geom.py:567-571) expanded in registers from the edge distance. */
+int mp_cfconv_gauss_fused_f32(const float* x, int64_t N, const float* dist, int bins, float distance, float sigma,
+                              float offset, const float* W1, const float* b1, const float* W2, const float* b2,
+                              const int32_t* recv_sorted, const int32_t* send, const int32_t* perm, int64_t M,
+                              int flags, float* out_zeroed, mpStream_t stream);
+
+/* Node-side chains of kgcnn/literature/Schnet.py:110-133 / schnet_conv.py:159-165 (F = 128, embedding width 64):
+ * node_in:     n = Embedding(Z) W0 + b0 ; x = n Wx
+ * node_update: n += ssp(agg W2 + b2) W3 + b3 ; x = n Wx_next ; agg := 0
+ * node_last:   n' = n + ssp(agg W2 + b2) W3 + b3 ; h = ssp(ssp(n' Wl0 + bl0) Wl1 + bl1) (N,64) ; agg := 0
+ * readout:     out[g] = ssp(sum_{nodes of g} h W_o0 + b_o0) W_o1 + b_o1   (PoolingNodes(sum) + MLP([64,1])) */
+int mp_schnet_node_in_f32(const float* numbers, int64_t N, const float* emb, int vocab, int emb_dim, const float* W0,
+                          const float* b0, const float* Wx, float* n_out, float* x_out, mpStream_t stream);
+int mp_schnet_node_update_f32(float* agg, int64_t N, const float* W2, const float* b2, const float* W3,
+                              const float* b3, float* n_inout, const float* Wx_next, float* x_out, mpStream_t stream);
+int mp_schnet_node_last_f32(float* agg, int64_t N, const float* W2, const float* b2, const float* W3, const float* b3,
+                            const float* n_in, const float* Wl0, const float* bl0, const float* Wl1, const float* bl1,
+                            float* h_out, mpStream_t stream);
+int mp_schnet_readout_f32(const float* h, const int64_t* node_splits, int64_t G, const float* Wo0, const float* bo0,
+                          const float* Wo1, const float* bo1, float* out, mpStream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,131 @@
+"""Fused SchNet kernels (csrc/mp_cfconv.hip, csrc/mp_schnet_node.hip) through the C ABI vs the CPU oracle."""
+import numpy as np
+import pytest
+import torch
+
+from gcnn_keras_amd import synth
+from oracle import kgcnn_oracle as ko
+
+pytestmark = pytest.mark.gpu
+
+
+def _rel_err(got, ref):
+    return float(np.max(np.abs(got - ref))) / max(float(np.max(np.abs(ref))), 1e-30)
+
+
+def _cfconv_case(seed, num_graphs=9, shuffle=False):
+    b = synth.qm9_like_batch(num_graphs=num_graphs, seed=seed)
+    rng = np.random.default_rng(seed)
+    idx = b["edge_indices"].copy()
+    if shuffle:  # destroy the receiver order inside every graph
+        for g in range(num_graphs):
+            lo, hi = b["edge_splits"][g], b["edge_splits"][g + 1]
+            idx[lo:hi] = idx[lo:hi][rng.permutation(hi - lo)]
+    n = int(b["node_splits"][-1])
+    x = ko.R(rng.normal(size=(n, 128)).astype(np.float32), b["node_splits"])
+    xyz = ko.R(b["node_coordinates"], b["node_splits"])
+    ridx = ko.R(idx, b["edge_splits"])
+    p1, p2 = ko.node_position(xyz, ridx)
+    dist = ko.node_distance_euclidean(p1, p2)
+    rbf = ko.gauss_basis(dist, 20, 4.0, 0.4)
+    p = {"dense1/kernel": synth.glorot_uniform(rng, 20, 128), "dense1/bias": rng.uniform(-.1, .1, 128).astype(np.float32),
+         "dense2/kernel": synth.glorot_uniform(rng, 128, 128),
+         "dense2/bias": rng.uniform(-.1, .1, 128).astype(np.float32)}
+    return b, x, ridx, dist, rbf, p
+
+
+@pytest.mark.parametrize("shuffle", [False, True])
+@pytest.mark.parametrize("variant", ["rbf", "gauss"])
+@pytest.mark.parametrize("fast", [0, 1])
+def test_cfconv_fused_vs_oracle(shuffle, variant, fast):
+    from gcnn_keras_amd import _ffi
+    from gcnn_keras_amd.ragged import RaggedTensor
+    b, x, ridx, dist, rbf, p = _cfconv_case(21, shuffle=shuffle)
+    ref = ko.schnet_cfconv(x, rbf, ridx, p).values
+    ref64 = ko.schnet_cfconv(ko.to_dtype(x, np.float64), ko.to_dtype(rbf, np.float64), ridx,
+                             ko.to_dtype(p, np.float64)).values
+    dx = RaggedTensor.from_numpy(x.values, x.row_splits)
+    di = RaggedTensor.from_numpy(ridx.values, ridx.row_splits)
+    plan = di.index_plan(dx)
+    ptr, perm, seg = plan.csr(0)
+    assert (perm is not None) == shuffle
+    n, m = plan.N, plan.M
+    out = torch.zeros((n, 128), dtype=torch.float32, device="cuda")
+    w = {k: torch.from_numpy(v).cuda() for k, v in p.items()}
+    send = plan.col(1).contiguous()
+    if variant == "rbf":
+        e = torch.from_numpy(rbf.values).cuda()
+        _ffi.call("mp_cfconv_fused_f32", _ffi.ptr(dx.values), n, _ffi.ptr(e), 20, _ffi.ptr(w["dense1/kernel"]),
+                  _ffi.ptr(w["dense1/bias"]), _ffi.ptr(w["dense2/kernel"]), _ffi.ptr(w["dense2/bias"]),
+                  _ffi.ptr(seg.contiguous()), _ffi.ptr(send), _ffi.ptr(perm), m, fast, _ffi.ptr(out), _ffi.stream())
+    else:
+        e = torch.from_numpy(dist.values.reshape(-1)).cuda()
+        _ffi.call("mp_cfconv_gauss_fused_f32", _ffi.ptr(dx.values), n, _ffi.ptr(e), 20, 4.0, 0.4, 0.0,
+                  _ffi.ptr(w["dense1/kernel"]), _ffi.ptr(w["dense1/bias"]), _ffi.ptr(w["dense2/kernel"]),
+                  _ffi.ptr(w["dense2/bias"]), _ffi.ptr(seg.contiguous()), _ffi.ptr(send), _ffi.ptr(perm), m, fast,
+                  _ffi.ptr(out), _ffi.stream())
+    got = out.cpu().numpy()
+    assert _rel_err(got, ref) <= 1e-5                       # north_star tolerance for the float segment-sum
+    assert _rel_err(got, ref64) <= max(4 * _rel_err(ref, ref64), 2e-6)
+
+
+def test_cfconv_no_bias_and_argument_checks():
+    from gcnn_keras_amd import _ffi
+    lib = _ffi.lib()
+    assert lib.mp_cfconv_fused_f32(None, 4, None, 40, None, None, None, None, None, None, None, 3, 0, None,
+                                   None) == _ffi.MP_EINVAL      # basis too wide for the fused kernel
+    assert lib.mp_cfconv_fused_f32(None, 0, None, 20, None, None, None, None, None, None, None, 0, 0, None,
+                                   None) == _ffi.MP_OK           # empty problem
+
+
+@pytest.mark.parametrize("num_graphs,seed,shuffle", [(6, 11, False), (1, 5, False), (128, 1234, False),
+                                                     (17, 3, True)])
+def test_fused_schnet_forward(num_graphs, seed, shuffle):
+    from gcnn_keras_amd.engine import SchnetForward
+    b = synth.qm9_like_batch(num_graphs=num_graphs, seed=seed)
+    if shuffle:
+        rng = np.random.default_rng(0)
+        idx = b["edge_indices"].copy()
+        for g in range(num_graphs):
+            lo, hi = b["edge_splits"][g], b["edge_splits"][g + 1]
+            idx[lo:hi] = idx[lo:hi][rng.permutation(hi - lo)]
+        b["edge_indices"] = idx
+    p = synth.schnet_params(seed=7, random_bias=True)
+    fwd = SchnetForward(p, depth=3, mode="fused")
+    assert fwd.mode == "fused"
+    fwd.load_batch(b)
+    out1 = fwd.forward().cpu().numpy().copy()
+    out2 = fwd.forward().cpu().numpy().copy()      # graph replay: same result, aggregation buffer was re-zeroed
+    fwd.check_flags()
+    assert np.array_equal(out1, out2)
+    ref = ko.schnet_forward(p, ko.R(b["node_number"], b["node_splits"]), ko.R(b["node_coordinates"], b["node_splits"]),
+                            ko.R(b["edge_indices"], b["edge_splits"]), depth=3)
+    ref64 = ko.schnet_forward(ko.to_dtype(p, np.float64), ko.R(b["node_number"], b["node_splits"]),
+                              ko.R(b["node_coordinates"].astype(np.float64), b["node_splits"]),
+                              ko.R(b["edge_indices"], b["edge_splits"]), depth=3)
+    assert out1.shape == ref.shape
+    assert _rel_err(out1, ref) <= 1e-5
+    assert _rel_err(out1, ref64) <= max(4 * _rel_err(ref, ref64), 2e-6)
+    # the layer-by-layer path gives the same answer within the same budget
+    lay = SchnetForward(p, depth=3, mode="layers")
+    lay.load_batch(b)
+    assert _rel_err(lay.forward().cpu().numpy(), out1) <= 1e-5
+
+
+def test_fused_schnet_empty_graphs_and_isolated_nodes():
+    from gcnn_keras_amd.engine import SchnetForward
+    b = synth.qm9_like_batch(num_graphs=5, seed=2)
+    # append a graph with 3 nodes and no edges, then an empty graph (dropped by PoolingNodes like TF does)
+    b["node_number"] = np.concatenate([b["node_number"], np.array([6., 1., 8.], np.float32)])
+    b["node_coordinates"] = np.concatenate([b["node_coordinates"], np.zeros((3, 3), np.float32)])
+    n, m = b["node_splits"][-1], b["edge_splits"][-1]
+    b["node_splits"] = np.concatenate([b["node_splits"], [n + 3, n + 3]])
+    b["edge_splits"] = np.concatenate([b["edge_splits"], [m, m]])
+    p = synth.schnet_params(seed=7, random_bias=True)
+    fwd = SchnetForward(p, depth=3, mode="fused")
+    fwd.load_batch(b)
+    out = fwd.forward().cpu().numpy()
+    ref = ko.schnet_forward(p, ko.R(b["node_number"], b["node_splits"]), ko.R(b["node_coordinates"], b["node_splits"]),
+                            ko.R(b["edge_indices"], b["edge_splits"]), depth=3)
+    assert out.shape == ref.shape == (6, 1)
+    assert _rel_err(out, ref) <= 1e-5
