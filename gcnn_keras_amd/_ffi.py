@@ -63,9 +63,11 @@ _SIGNATURES = {
     "mp_edge_geometry_f32": [P, c_int64, P, P, c_int64, P, P, P],
     "mp_ragged_to_padded_f32": [P, P, c_int64, c_int64, c_int64, P, P, P],
     "mp_edge_prepare_i64_f32": [P, c_int64, P, P, c_int64, c_int64, P, P, P, P, P, P],
-    "mp_cfconv_fused_f32": [P, c_int64, P, c_int, P, P, P, P, P, P, P, c_int64, c_int, P, P],
-    "mp_cfconv_gauss_fused_f32": [P, c_int64, P, c_int, c_float, c_float, c_float, P, P, P, P, P, P, P, c_int64,
-                                  c_int, P, P],
+    "mp_cfconv_packed_floats": [],
+    "mp_cfconv_pack_f32": [P, P, c_int, P, P, P, P],
+    "mp_cfconv_fused_f32": [P, c_int64, P, c_int, P, P, P, P, c_int64, c_int, P, P],
+    "mp_cfconv_gauss_fused_f32": [P, c_int64, P, c_int, c_float, c_float, c_float, P, P, P, P, c_int64, c_int, P, P],
+    "mp_cfconv_gauss_diag_f32": [P, c_int64, P, c_int, c_float, c_float, c_float, P, P, P, P, c_int64, P, P, P],
     "mp_schnet_node_in_f32": [P, c_int64, P, c_int, c_int, P, P, P, P, P, P],
     "mp_schnet_node_update_f32": [P, c_int64, P, P, P, P, P, P, P, P],
     "mp_schnet_node_last_f32": [P, c_int64, P, P, P, P, P, P, P, P, P, P, P],

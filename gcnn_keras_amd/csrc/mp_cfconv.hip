@@ -46,18 +46,17 @@ __device__ __forceinline__ int rowmap(int r, int hh) { return (r & 3) + 8 * (r >
 // shifted softplus, kgcnn/ops/activ.py:15, in the form max(x,0) + log1p(exp(-|x|)) - log(2): identical to TF's
 // thresholded log1p(exp(x)) up to float rounding (|delta| < 2e-7 absolute) and free of overflow.
 __device__ __forceinline__ float ssp_fast(float x) {
-  const float t = __expf(-fabsf(x));
-  return fmaxf(x, 0.0f) + __logf(1.0f + t) - 0.6931471805599453f;
+  // v_exp_f32 / v_log_f32 are base-2: t = 2^(-|x| log2 e), ssp = max(x,0) + ln2 * (log2(1 + t) - 1)
+  const float t = __builtin_amdgcn_exp2f(fabsf(x) * -1.4426950408889634f);
+  const float l = __builtin_amdgcn_logf(1.0f + t);
+  return fmaf(l - 1.0f, 0.6931471805599453f, fmaxf(x, 0.0f));
 }
 __device__ __forceinline__ float ssp_exact(float x) { return mp_softplus(x) - 0.6931471805599453f; }
 
 struct CfconvArgs {
   const float* x;         // (N, F) sender-side node features
   const float* edge_in;   // GAUSS: dist (M) ; else rbf (M, B)
-  const float* W1;        // (B, F)
-  const float* b1;        // (F) or null
-  const float* W2;        // (F, F)
-  const float* b2;        // (F) or null
+  const float* packed;    // mp_cfconv_pack_f32 output: [MAX_KROWS][F] W1|b1 rows, [F][F] W2, [F] b2 (LDS image order)
   const int32_t* recv;    // (M) receiver ids, ascending (already permuted if perm != null)
   const int32_t* send;    // (M) sender ids in original edge order
   const int32_t* perm;    // (M) sorted position -> original edge, or null
@@ -66,10 +65,24 @@ struct CfconvArgs {
   int B;
   float g_distance, g_gamma, g_offset;  // Gauss basis parameters (geom.py:567-571)
   int ntiles;
+  unsigned long long* diag;  // optional [8] cycle sums per phase (diagnostic build only)
 };
 
-template <int WAVES, bool GAUSS, bool FAST_SSP>
+#define MP_STAMP(idx)                                                                  \
+  if constexpr (DIAG) {                                                                \
+    __builtin_amdgcn_sched_barrier(0);                                                 \
+    const unsigned long long t_now = __builtin_amdgcn_s_memtime();                     \
+    __builtin_amdgcn_s_waitcnt(0xC07F);                                                \
+    __builtin_amdgcn_sched_barrier(0);                                                 \
+    diag_sum[idx] += t_now - t_prev;                                                   \
+    t_prev = t_now;                                                                    \
+  }
+
+template <int WAVES, bool GAUSS, bool FAST_SSP, int NKT, bool DIAG = false>
 __global__ __launch_bounds__(WAVES * 64) void cfconv_fused_kernel(CfconvArgs a) {
+  unsigned long long diag_sum[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  unsigned long long t_prev = 0;
+  if constexpr (DIAG) t_prev = __builtin_amdgcn_s_memtime();
   extern __shared__ __align__(16) float lds[];
   float* W1s = lds;                          // [MAX_KROWS][F] packed
   float* W2s = lds + MAX_KROWS * F;          // [F][F] packed
@@ -81,32 +94,22 @@ __global__ __launch_bounds__(WAVES * 64) void cfconv_fused_kernel(CfconvArgs a) 
   const int c = lane & 31;
   const int hh = lane >> 5;
   const int B = a.B;
-  const int nk = (B + 2) >> 1;  // k-steps of GEMM1: B inputs + 1 bias row, two k per step
+  // k-steps of GEMM1: B inputs + 1 bias row, two k per step; NKT > 0 fixes it at compile time (B = 20 -> 11)
+  const int nk = NKT > 0 ? NKT : ((B + 2) >> 1);
+  constexpr int NKMAX = NKT > 0 ? NKT : MAX_KROWS / 2;
 
-  // ---- stage the weights once per workgroup: LDS[k][4*c + blk] = W[k][blk*32 + c] ---------------------------
-  for (int i = tid; i < 2 * nk * 32; i += WAVES * 64) {
-    const int k = i >> 5, cc = i & 31;
-    float4 v;
-    if (k < B) {
-      v = make_float4(a.W1[k * F + cc], a.W1[k * F + 32 + cc], a.W1[k * F + 64 + cc], a.W1[k * F + 96 + cc]);
-    } else if (k == B && a.b1) {
-      v = make_float4(a.b1[cc], a.b1[32 + cc], a.b1[64 + cc], a.b1[96 + cc]);
-    } else {
-      v = make_float4(0.f, 0.f, 0.f, 0.f);
-    }
-    *reinterpret_cast<float4*>(W1s + k * F + 4 * cc) = v;
-  }
-  for (int i = tid; i < F * 32; i += WAVES * 64) {
-    const int k = i >> 5, cc = i & 31;
-    const float4 v = make_float4(a.W2[k * F + cc], a.W2[k * F + 32 + cc], a.W2[k * F + 64 + cc],
-                                 a.W2[k * F + 96 + cc]);
-    *reinterpret_cast<float4*>(W2s + k * F + 4 * cc) = v;
+  // ---- stage the pre-packed weights once per workgroup: a straight 16-byte copy into the LDS image ---------------
+  {
+    const float4* src = reinterpret_cast<const float4*>(a.packed);
+    float4* dst = reinterpret_cast<float4*>(lds);
+    for (int i = tid; i < (MAX_KROWS * F + F * F) / 4; i += WAVES * 64) dst[i] = src[i];
   }
   float bias2[4];
 #pragma unroll
-  for (int jb = 0; jb < 4; ++jb) bias2[jb] = a.b2 ? a.b2[jb * 32 + c] : 0.0f;
+  for (int jb = 0; jb < 4; ++jb) bias2[jb] = a.packed[MAX_KROWS * F + F * F + jb * 32 + c];
   __syncthreads();
 
+  MP_STAMP(0)
   float* T = Ts + wave * (F * T_LD);
   const float* w1_lane = W1s + (nk * hh) * F + 4 * c;  // + s*F           : rows s (lo half) / nk+s (hi half)
   const float* w2_lane = W2s + (4 * hh) * F + 4 * c;   // + (ib*32 + (r&3) + 8*(r>>2))*F
@@ -119,24 +122,30 @@ __global__ __launch_bounds__(WAVES * 64) void cfconv_fused_kernel(CfconvArgs a) 
     const int64_t e_clamped = valid ? e_mine : a.M - 1;
     const int64_t ep = a.perm ? static_cast<int64_t>(a.perm[e_clamped]) : e_clamped;
     const int my_send = a.send[ep];
+    const int my_recv = a.recv[e_clamped];
 
     // ---- B operand of GEMM1: this lane's half of its edge's basis row (+ the constant 1 of the bias row) ----
-    float rb[MAX_KROWS / 2];
+    float rb[NKMAX];
     if constexpr (GAUSS) {
       const float d = a.edge_in[ep];
       const float fbins = static_cast<float>(B);
 #pragma unroll
-      for (int s = 0; s < MAX_KROWS / 2; ++s) {
+      for (int s = 0; s < NKMAX; ++s) {
         const int k = s + nk * hh;
         const float mu = static_cast<float>(k) / fbins * a.g_distance;
         const float v = (d - a.g_offset) - mu;
-        float val = expf((v * v) * (a.g_gamma * -1.0f));
+        float val;
+        if constexpr (FAST_SSP) {
+          val = __builtin_amdgcn_exp2f((v * v) * (a.g_gamma * -1.4426950408889634f));  // v_exp_f32: 2^(x log2 e)
+        } else {
+          val = expf((v * v) * (a.g_gamma * -1.0f));
+        }
         val = k < B ? val : (k == B ? 1.0f : 0.0f);
         rb[s] = (s < nk && valid) ? val : 0.0f;
       }
     } else {
 #pragma unroll
-      for (int s = 0; s < MAX_KROWS / 2; ++s) {
+      for (int s = 0; s < NKMAX; ++s) {
         const int k = s + nk * hh;
         float val = 0.0f;
         if (s < nk && valid) val = k < B ? a.edge_in[ep * B + k] : (k == B ? 1.0f : 0.0f);
@@ -144,6 +153,7 @@ __global__ __launch_bounds__(WAVES * 64) void cfconv_fused_kernel(CfconvArgs a) 
       }
     }
 
+    MP_STAMP(1)
     // ---- GEMM1 (transposed): hT[f][e] = sum_k W1p[k][f] * rb[e][k]; lane = edge, register = feature ---------
     floatx16 h[4];
 #pragma unroll
@@ -151,7 +161,7 @@ __global__ __launch_bounds__(WAVES * 64) void cfconv_fused_kernel(CfconvArgs a) 
 #pragma unroll
       for (int r = 0; r < 16; ++r) h[ib][r] = 0.0f;
 #pragma unroll
-    for (int s = 0; s < MAX_KROWS / 2; ++s) {
+    for (int s = 0; s < NKMAX; ++s) {
       if (s < nk) {
         const float4 wv = *reinterpret_cast<const float4*>(w1_lane + s * F);
         h[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(wv.x, rb[s], h[0], 0, 0, 0);
@@ -160,11 +170,28 @@ __global__ __launch_bounds__(WAVES * 64) void cfconv_fused_kernel(CfconvArgs a) 
         h[3] = __builtin_amdgcn_mfma_f32_32x32x2f32(wv.w, rb[s], h[3], 0, 0, 0);
       }
     }
+    MP_STAMP(2)
 #pragma unroll
     for (int ib = 0; ib < 4; ++ib)
 #pragma unroll
       for (int r = 0; r < 16; ++r) h[ib][r] = FAST_SSP ? ssp_fast(h[ib][r]) : ssp_exact(h[ib][r]);
 
+    // ---- sender rows, issued now so that their latency hides under GEMM2 (coalesced 128-B reads per half wave) ---
+    float xv[4][16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int row = rowmap(r, hh);
+      const int snode = __shfl(my_send, row, 64);
+      const bool row_valid = (e0 + row) < a.M;
+      const float* xrow = a.x + static_cast<int64_t>(snode) * F + c;
+#pragma unroll
+      for (int jb = 0; jb < 4; ++jb) {
+        const float t = xrow[jb * 32];  // always in range: padding rows reuse the last valid edge's sender
+        xv[jb][r] = row_valid ? t : 0.0f;
+      }
+    }
+
+    MP_STAMP(3)
     // ---- GEMM2: w[e][j] = sum_f h[e][f] W2[f][j] + b2[j]; A = the accumulator registers of GEMM1 ------------
     floatx16 w[4];
 #pragma unroll
@@ -185,28 +212,18 @@ __global__ __launch_bounds__(WAVES * 64) void cfconv_fused_kernel(CfconvArgs a) 
       }
     }
 
-    // ---- multiply by the sender row (coalesced 128-B reads) and transpose into the slab [feature][edge] -------
+    MP_STAMP(4)
+    // ---- multiply by the sender row and transpose into the slab [feature][edge] ----------------------------------
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
-      float4 m[4];
-      float* mp = reinterpret_cast<float*>(m);
 #pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        const int r = q * 4 + i;
-        const int row = rowmap(r, hh);
-        const int snode = __shfl(my_send, row, 64);
-        const bool row_valid = (e0 + row) < a.M;
-        const float* xrow = a.x + static_cast<int64_t>(snode) * F + c;
-#pragma unroll
-        for (int jb = 0; jb < 4; ++jb) {
-          const float xv = row_valid ? xrow[jb * 32] : 0.0f;
-          mp[jb * 4 + i] = w[jb][r] * xv;
-        }
+      for (int jb = 0; jb < 4; ++jb) {
+        const float4 m = make_float4(w[jb][4 * q] * xv[jb][4 * q], w[jb][4 * q + 1] * xv[jb][4 * q + 1],
+                                     w[jb][4 * q + 2] * xv[jb][4 * q + 2], w[jb][4 * q + 3] * xv[jb][4 * q + 3]);
+        *reinterpret_cast<float4*>(T + (jb * 32 + c) * T_LD + 8 * q + 4 * hh) = m;
       }
-#pragma unroll
-      for (int jb = 0; jb < 4; ++jb)
-        *reinterpret_cast<float4*>(T + (jb * 32 + c) * T_LD + 8 * q + 4 * hh) = m[jb];
     }
+    MP_STAMP(5)
     // the slab is private to this wave: LDS operations of one wave complete in order, no barrier needed
     float va[TE], vb[TE];
 #pragma unroll
@@ -217,16 +234,19 @@ __global__ __launch_bounds__(WAVES * 64) void cfconv_fused_kernel(CfconvArgs a) 
       vb[4 * q] = tb.x; vb[4 * q + 1] = tb.y; vb[4 * q + 2] = tb.z; vb[4 * q + 3] = tb.w;
     }
 
-    // ---- in-order segmented sum over the 32 edges; receiver ids are wave-uniform --------------------------
-    const int64_t last = a.M - 1;
-    int cur = a.recv[e0];
+    MP_STAMP(6)
+    // ---- in-order segmented sum over the 32 edges.  Segment starts come from one ballot (a scalar bit mask), the
+    //      receiver ids from v_readlane: no memory access and only scalar branches inside the walk.  Padding edges
+    //      of the last tile repeat the last receiver and carry zeros. ---------------------------------------------
+    const int prev_recv = __shfl_up(my_recv, 1, 64);  // all lanes take part; lanes 0 / 32 are masked out below
+    const unsigned start_mask =
+        static_cast<unsigned>(__ballot((c > 0) & (my_recv != prev_recv)) & 0xffffffffull);
     float sa = va[0], sb = vb[0];
     bool first = true;
 #pragma unroll
     for (int i = 1; i < TE; ++i) {
-      const int64_t ei = (e0 + i) <= last ? (e0 + i) : last;  // padding edges carry zeros into the last segment
-      const int ri = a.recv[ei];
-      if (ri != cur) {
+      if ((start_mask >> i) & 1u) {
+        const int cur = __builtin_amdgcn_readlane(my_recv, i - 1);
         float* dst = a.out + static_cast<int64_t>(cur) * F + lane;
         if (first) {
           atomicAdd(dst, sa);
@@ -236,7 +256,6 @@ __global__ __launch_bounds__(WAVES * 64) void cfconv_fused_kernel(CfconvArgs a) 
           dst[0] = sa;
           dst[64] = sb;
         }
-        cur = ri;
         sa = va[i];
         sb = vb[i];
       } else {
@@ -244,9 +263,44 @@ __global__ __launch_bounds__(WAVES * 64) void cfconv_fused_kernel(CfconvArgs a) 
         sb += vb[i];
       }
     }
-    float* dst = a.out + static_cast<int64_t>(cur) * F + lane;
-    atomicAdd(dst, sa);
-    atomicAdd(dst + 64, sb);
+    {
+      const int cur = __builtin_amdgcn_readlane(my_recv, TE - 1);
+      float* dst = a.out + static_cast<int64_t>(cur) * F + lane;
+      atomicAdd(dst, sa);
+      atomicAdd(dst + 64, sb);
+    }
+    MP_STAMP(7)
+  }
+  if constexpr (DIAG) {
+    if (lane == 0 && a.diag) {
+#pragma unroll
+      for (int i = 0; i < 8; ++i) atomicAdd(a.diag + i, diag_sum[i]);
+    }
+  }
+}
+
+constexpr int PACKED_FLOATS = MAX_KROWS * F + F * F + F;
+
+// LDS image of the filter-MLP weights: row k of W1 (k < B), the bias b1 as row B, zero rows up to MAX_KROWS, then W2,
+// every row stored [4*c + blk] = W[k][blk*32 + c]; finally b2 in natural order.
+__global__ void cfconv_pack_kernel(const float* __restrict__ W1, const float* __restrict__ b1, int B,
+                                   const float* __restrict__ W2, const float* __restrict__ b2,
+                                   float* __restrict__ packed) {
+  const int stride = gridDim.x * blockDim.x;
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < PACKED_FLOATS; i += stride) {
+    float v = 0.0f;
+    if (i < MAX_KROWS * F) {
+      const int k = i / F, col = (i % F) / 4 + 32 * (i % 4);
+      if (k < B) v = W1[k * F + col];
+      else if (k == B && b1) v = b1[col];
+    } else if (i < MAX_KROWS * F + F * F) {
+      const int j = i - MAX_KROWS * F;
+      const int k = j / F, col = (j % F) / 4 + 32 * (j % 4);
+      v = W2[k * F + col];
+    } else {
+      v = b2 ? b2[i - MAX_KROWS * F - F * F] : 0.0f;
+    }
+    packed[i] = v;
   }
 }
 
@@ -255,17 +309,23 @@ size_t cfconv_lds_bytes() {
   return sizeof(float) * (MAX_KROWS * F + F * F + WAVES * F * T_LD);
 }
 
-template <int WAVES, bool GAUSS, bool FAST>
+template <int WAVES, bool GAUSS, bool FAST, int NKT, bool DIAG>
 int launch_cfconv(const CfconvArgs& args, int grid, hipStream_t s) {
   const size_t lds = cfconv_lds_bytes<WAVES>();
   static bool attr_set = false;
   if (!attr_set) {
-    MP_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&cfconv_fused_kernel<WAVES, GAUSS, FAST>),
+    MP_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&cfconv_fused_kernel<WAVES, GAUSS, FAST, NKT, DIAG>),
                                hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds)));
     attr_set = true;
   }
-  cfconv_fused_kernel<WAVES, GAUSS, FAST><<<grid, WAVES * 64, lds, s>>>(args);
+  cfconv_fused_kernel<WAVES, GAUSS, FAST, NKT, DIAG><<<grid, WAVES * 64, lds, s>>>(args);
   return mp::check_launch("mp_cfconv_fused_f32");
+}
+
+template <bool GAUSS, bool FAST>
+int launch_by_basis(const CfconvArgs& args, int grid, hipStream_t s) {
+  if (args.B == 20) return launch_cfconv<4, GAUSS, FAST, 11, false>(args, grid, s);  // SchNet default: 20 bins
+  return launch_cfconv<4, GAUSS, FAST, 0, false>(args, grid, s);
 }
 
 int cfconv_dispatch(CfconvArgs args, bool gauss, int flags, hipStream_t s) {
@@ -273,47 +333,76 @@ int cfconv_dispatch(CfconvArgs args, bool gauss, int flags, hipStream_t s) {
   MP_REQUIRE(args.B >= 1 && args.B <= MAX_KROWS - 2, "mp_cfconv: basis size B=%d must be in 1..%d", args.B,
              MAX_KROWS - 2);
   if (args.M == 0 || args.N == 0) return MP_OK;
-  MP_REQUIRE(args.x && args.edge_in && args.W1 && args.W2 && args.recv && args.send && args.out,
-             "mp_cfconv: null pointer");
+  MP_REQUIRE(args.x && args.edge_in && args.packed && args.recv && args.send && args.out, "mp_cfconv: null pointer");
   MP_REQUIRE(args.M < (int64_t{1} << 31), "mp_cfconv: M must fit int32");
   args.ntiles = static_cast<int>((args.M + TE - 1) / TE);
   const bool fast = (flags & 1) != 0;
   // one workgroup per CU (LDS holds the weights); persistent over the tiles
   int grid = (args.ntiles + 3) / 4;
   if (grid > 256) grid = 256;
-  if (gauss) {
-    return fast ? launch_cfconv<4, true, true>(args, grid, s) : launch_cfconv<4, true, false>(args, grid, s);
+  if (args.diag) {
+    MP_REQUIRE(gauss && args.B == 20, "mp_cfconv: the diagnostic build exists for the 20-bin Gauss variant only");
+    return launch_cfconv<4, true, true, 11, true>(args, grid, s);
   }
-  return fast ? launch_cfconv<4, false, true>(args, grid, s) : launch_cfconv<4, false, false>(args, grid, s);
+  if (gauss) return fast ? launch_by_basis<true, true>(args, grid, s) : launch_by_basis<true, false>(args, grid, s);
+  return fast ? launch_by_basis<false, true>(args, grid, s) : launch_by_basis<false, false>(args, grid, s);
 }
 
 }  // namespace
 
 extern "C" {
 
-int mp_cfconv_fused_f32(const float* x, int64_t N, const float* rbf, int B, const float* W1, const float* b1,
-                        const float* W2, const float* b2, const int32_t* recv_sorted, const int32_t* send,
-                        const int32_t* perm, int64_t M, int flags, float* out_zeroed, mpStream_t stream) {
+int mp_cfconv_packed_floats(void) { return PACKED_FLOATS; }
+
+int mp_cfconv_pack_f32(const float* W1, const float* b1, int B, const float* W2, const float* b2, float* packed,
+                       mpStream_t stream) {
+  MP_REQUIRE(B >= 1 && B <= MAX_KROWS - 2, "mp_cfconv_pack_f32: basis size B=%d must be in 1..%d", B, MAX_KROWS - 2);
+  MP_REQUIRE(W1 && W2 && packed, "mp_cfconv_pack_f32: null pointer");
+  cfconv_pack_kernel<<<64, 256, 0, mp::as_stream(stream)>>>(W1, b1, B, W2, b2, packed);
+  return mp::check_launch("mp_cfconv_pack_f32");
+}
+
+int mp_cfconv_fused_f32(const float* x, int64_t N, const float* rbf, int B, const float* packed,
+                        const int32_t* recv_sorted, const int32_t* send, const int32_t* perm, int64_t M, int flags,
+                        float* out_zeroed, mpStream_t stream) {
   CfconvArgs a{};
-  a.x = x; a.edge_in = rbf; a.W1 = W1; a.b1 = b1; a.W2 = W2; a.b2 = b2;
+  a.x = x; a.edge_in = rbf; a.packed = packed;
   a.recv = recv_sorted; a.send = send; a.perm = perm; a.out = out_zeroed;
   a.M = M; a.N = N; a.B = B;
   return cfconv_dispatch(a, false, flags, mp::as_stream(stream));
 }
 
 int mp_cfconv_gauss_fused_f32(const float* x, int64_t N, const float* dist, int bins, float distance, float sigma,
-                              float offset, const float* W1, const float* b1, const float* W2, const float* b2,
-                              const int32_t* recv_sorted, const int32_t* send, const int32_t* perm, int64_t M,
-                              int flags, float* out_zeroed, mpStream_t stream) {
+                              float offset, const float* packed, const int32_t* recv_sorted, const int32_t* send,
+                              const int32_t* perm, int64_t M, int flags, float* out_zeroed, mpStream_t stream) {
   MP_REQUIRE(sigma != 0.0f, "mp_cfconv_gauss_fused_f32: sigma must be non-zero");
   CfconvArgs a{};
-  a.x = x; a.edge_in = dist; a.W1 = W1; a.b1 = b1; a.W2 = W2; a.b2 = b2;
+  a.x = x; a.edge_in = dist; a.packed = packed;
   a.recv = recv_sorted; a.send = send; a.perm = perm; a.out = out_zeroed;
   a.M = M; a.N = N; a.B = bins;
   a.g_distance = distance;
   a.g_gamma = static_cast<float>(1.0 / static_cast<double>(sigma) / static_cast<double>(sigma) / 2.0);
   a.g_offset = offset;
   return cfconv_dispatch(a, true, flags, mp::as_stream(stream));
+}
+
+// Diagnostic build of the 20-bin Gauss variant (fast softplus): adds per-phase s_memtime sums (8 x uint64,
+// caller-zeroed) for lane 0 of every wave.  Its run time is not representative (the stamps fence the schedule); read
+// the SHARES only.
+int mp_cfconv_gauss_diag_f32(const float* x, int64_t N, const float* dist, int bins, float distance, float sigma,
+                             float offset, const float* packed, const int32_t* recv_sorted, const int32_t* send,
+                             const int32_t* perm, int64_t M, float* out_zeroed, unsigned long long* diag8,
+                             mpStream_t stream) {
+  MP_REQUIRE(sigma != 0.0f && diag8, "mp_cfconv_gauss_diag_f32: bad arguments");
+  CfconvArgs a{};
+  a.x = x; a.edge_in = dist; a.packed = packed;
+  a.recv = recv_sorted; a.send = send; a.perm = perm; a.out = out_zeroed;
+  a.M = M; a.N = N; a.B = bins;
+  a.g_distance = distance;
+  a.g_gamma = static_cast<float>(1.0 / static_cast<double>(sigma) / static_cast<double>(sigma) / 2.0);
+  a.g_offset = offset;
+  a.diag = diag8;
+  return cfconv_dispatch(a, true, 1, mp::as_stream(stream));
 }
 
 }  // extern "C"

@@ -136,6 +136,6 @@ class SchnetForward:
 def _fused_available():
     try:
         lib = _ffi.lib()
-        return hasattr(lib, "mp_schnet_cfconv_fused_f32")
+        return hasattr(lib, "mp_cfconv_gauss_fused_f32")
     except Exception:
         return False

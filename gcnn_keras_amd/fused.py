@@ -30,7 +30,7 @@ def supports(config):
 
 
 class FusedSchnet:
-    def __init__(self, params, depth=3, gauss_args=None, fast_softplus=False, use_graph=True):
+    def __init__(self, params, depth=3, gauss_args=None, fast_softplus=True, use_graph=True):
         if not torch.cuda.is_available():
             raise _ffi.EngineError("FusedSchnet needs an MI355X (no CPU fallback)")
         self.depth = depth
@@ -40,6 +40,18 @@ class FusedSchnet:
         self.p = {k: torch.from_numpy(np.ascontiguousarray(v, dtype=np.float32)).cuda() for k, v in params.items()}
         if tuple(self.p["embedding"].shape)[1] != 64 or tuple(self.p["dense0/kernel"].shape) != (64, 128):
             raise ValueError("FusedSchnet is built for embedding width 64 and 128 units")
+        # filter-MLP weights of every block in the cfconv kernel's LDS image order (packed once per weight update)
+        nfl = _ffi.lib().mp_cfconv_packed_floats()
+        self.packed = []
+        for i in range(depth):
+            pre = "interaction%d/cfconv/" % i
+            buf = torch.empty(nfl, dtype=torch.float32, device="cuda")
+            _ffi.call("mp_cfconv_pack_f32", _ffi.ptr(self.p[pre + "dense1/kernel"]),
+                      _ffi.ptr(self.p.get(pre + "dense1/bias")), int(self.gauss["bins"]),
+                      _ffi.ptr(self.p[pre + "dense2/kernel"]), _ffi.ptr(self.p.get(pre + "dense2/bias")),
+                      _ffi.ptr(buf), _ffi.stream())
+            self.packed.append(buf)
+        torch.cuda.synchronize()
         self.stream = torch.cuda.Stream()
         self.graph = None
         self.num_launches = 2 + 2 * depth + 1
@@ -90,13 +102,10 @@ class FusedSchnet:
                   _ffi.ptr(self.flags), _ffi.stream())
 
     def _cfconv(self, i, out):
-        p, ga = self.p, self.gauss
-        pre = "interaction%d/cfconv/" % i
+        ga = self.gauss
         recv = self.recv if self.sorted else self.recv_sorted
         _ffi.call("mp_cfconv_gauss_fused_f32", _ffi.ptr(self.x), self.N, _ffi.ptr(self.dist), int(ga["bins"]),
-                  float(ga["distance"]), float(ga["sigma"]), float(ga["offset"]),
-                  _ffi.ptr(p[pre + "dense1/kernel"]), _ffi.ptr(p.get(pre + "dense1/bias")),
-                  _ffi.ptr(p[pre + "dense2/kernel"]), _ffi.ptr(p.get(pre + "dense2/bias")),
+                  float(ga["distance"]), float(ga["sigma"]), float(ga["offset"]), _ffi.ptr(self.packed[i]),
                   _ffi.ptr(recv), _ffi.ptr(self.send), _ffi.ptr(self.perm), self.M, self.flags_arg, _ffi.ptr(out),
                   _ffi.stream())
 

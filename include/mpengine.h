@@ -186,16 +186,29 @@ int mp_edge_prepare_i64_f32(const int64_t* idx, int64_t M, const int64_t* node_s
 
 /* SchNetCFconv.call, kgcnn/layers/conv/schnet_conv.py:73-79, fused (F = units = 128, cfconv_pool = sum,
  * activation = shifted_softplus): out[i] += sum_{e: recv[e]=i} x[send[e]] * (ssp(rbf[e] W1 + b1) W2 + b2).
+ * The filter-MLP weights (Keras layouts W1 (B,128), b1 (128)|NULL, W2 (128,128), b2 (128)|NULL) are packed once
+ * per weight update into the kernel's LDS image by mp_cfconv_pack_f32 (mp_cfconv_packed_floats() floats).
  * recv_sorted ascending; perm (nullable) maps sorted position -> original edge (rbf / send are in original
  * order); out (N,128) must be zero on entry.  flags bit0: fast softplus (v_exp/v_log form, |delta| < 2e-7). */
-int mp_cfconv_fused_f32(const float* x, int64_t N, const float* rbf, int B, const float* W1, const float* b1,
-                        const float* W2, const float* b2, const int32_t* recv_sorted, const int32_t* send,
-                        const int32_t* perm, int64_t M, int flags, float* out_zeroed, mpStream_t stream);
+int mp_cfconv_packed_floats(void);
+int mp_cfconv_pack_f32(const float* W1, const float* b1, int B, const float* W2, const float* b2, float* packed,
+                       mpStream_t stream);
+int mp_cfconv_fused_f32(const float* x, int64_t N, const float* rbf, int B, const float* packed,
+                        const int32_t* recv_sorted, const int32_t* send, const int32_t* perm, int64_t M, int flags,
+                        float* out_zeroed, mpStream_t stream);
 /* Same with GaussBasisLayer (kgcnn/layers/geom.py:567-571) expanded in registers from the edge distance. */
 int mp_cfconv_gauss_fused_f32(const float* x, int64_t N, const float* dist, int bins, float distance, float sigma,
-                              float offset, const float* W1, const float* b1, const float* W2, const float* b2,
-                              const int32_t* recv_sorted, const int32_t* send, const int32_t* perm, int64_t M,
-                              int flags, float* out_zeroed, mpStream_t stream);
+                              float offset, const float* packed, const int32_t* recv_sorted, const int32_t* send,
+                              const int32_t* perm, int64_t M, int flags, float* out_zeroed, mpStream_t stream);
+
+/* Diagnostic build of mp_cfconv_gauss_fused_f32 (20 bins, fast softplus): adds per-phase shader-cycle sums into
+ * diag8 (8 x uint64, caller-zeroed): [0] weight staging, [1] tile setup + Gauss basis, [2] GEMM1, [3] softplus +
+ * sender-row loads issued, [4] GEMM2, [5] multiply + slab write, [6] slab read, [7] segmented sum + stores/atomics.
+ * Shares only: the stamps fence the schedule. */
+int mp_cfconv_gauss_diag_f32(const float* x, int64_t N, const float* dist, int bins, float distance, float sigma,
+                             float offset, const float* packed, const int32_t* recv_sorted, const int32_t* send,
+                             const int32_t* perm, int64_t M, float* out_zeroed, unsigned long long* diag8,
+                             mpStream_t stream);
 
 /* Node-side chains of kgcnn/literature/Schnet.py:110-133 / schnet_conv.py:159-165 (F = 128, embedding width 64):
  * node_in:     n = Embedding(Z) W0 + b0 ; x = n Wx

@@ -53,16 +53,17 @@ def test_cfconv_fused_vs_oracle(shuffle, variant, fast):
     out = torch.zeros((n, 128), dtype=torch.float32, device="cuda")
     w = {k: torch.from_numpy(v).cuda() for k, v in p.items()}
     send = plan.col(1).contiguous()
+    packed = torch.empty(_ffi.lib().mp_cfconv_packed_floats(), dtype=torch.float32, device="cuda")
+    _ffi.call("mp_cfconv_pack_f32", _ffi.ptr(w["dense1/kernel"]), _ffi.ptr(w["dense1/bias"]), 20,
+              _ffi.ptr(w["dense2/kernel"]), _ffi.ptr(w["dense2/bias"]), _ffi.ptr(packed), _ffi.stream())
     if variant == "rbf":
         e = torch.from_numpy(rbf.values).cuda()
-        _ffi.call("mp_cfconv_fused_f32", _ffi.ptr(dx.values), n, _ffi.ptr(e), 20, _ffi.ptr(w["dense1/kernel"]),
-                  _ffi.ptr(w["dense1/bias"]), _ffi.ptr(w["dense2/kernel"]), _ffi.ptr(w["dense2/bias"]),
+        _ffi.call("mp_cfconv_fused_f32", _ffi.ptr(dx.values), n, _ffi.ptr(e), 20, _ffi.ptr(packed),
                   _ffi.ptr(seg.contiguous()), _ffi.ptr(send), _ffi.ptr(perm), m, fast, _ffi.ptr(out), _ffi.stream())
     else:
         e = torch.from_numpy(dist.values.reshape(-1)).cuda()
         _ffi.call("mp_cfconv_gauss_fused_f32", _ffi.ptr(dx.values), n, _ffi.ptr(e), 20, 4.0, 0.4, 0.0,
-                  _ffi.ptr(w["dense1/kernel"]), _ffi.ptr(w["dense1/bias"]), _ffi.ptr(w["dense2/kernel"]),
-                  _ffi.ptr(w["dense2/bias"]), _ffi.ptr(seg.contiguous()), _ffi.ptr(send), _ffi.ptr(perm), m, fast,
+                  _ffi.ptr(packed), _ffi.ptr(seg.contiguous()), _ffi.ptr(send), _ffi.ptr(perm), m, fast,
                   _ffi.ptr(out), _ffi.stream())
     got = out.cpu().numpy()
     assert _rel_err(got, ref) <= 1e-5                       # north_star tolerance for the float segment-sum
@@ -72,9 +73,9 @@ def test_cfconv_fused_vs_oracle(shuffle, variant, fast):
 def test_cfconv_no_bias_and_argument_checks():
     from gcnn_keras_amd import _ffi
     lib = _ffi.lib()
-    assert lib.mp_cfconv_fused_f32(None, 4, None, 40, None, None, None, None, None, None, None, 3, 0, None,
+    assert lib.mp_cfconv_fused_f32(None, 4, None, 40, None, None, None, None, 3, 0, None,
                                    None) == _ffi.MP_EINVAL      # basis too wide for the fused kernel
-    assert lib.mp_cfconv_fused_f32(None, 0, None, 20, None, None, None, None, None, None, None, 0, 0, None,
+    assert lib.mp_cfconv_fused_f32(None, 0, None, 20, None, None, None, None, 0, 0, None,
                                    None) == _ffi.MP_OK           # empty problem
 
 
