@@ -98,6 +98,25 @@ __global__ __launch_bounds__(WAVES * 64) void cfconv_fused_kernel(CfconvArgs a) 
   const int nk = NKT > 0 ? NKT : ((B + 2) >> 1);
   constexpr int NKMAX = NKT > 0 ? NKT : MAX_KROWS / 2;
 
+  // ---- per-tile edge data is fetched one tile ahead (the first tile's before the weight staging) so that its
+  //      latency (perm -> send / dist is a dependent chain) hides under staging resp. the previous tile's MFMAs -----
+  const int tile_first = blockIdx.x * WAVES + wave;
+  const int tile_step = gridDim.x * WAVES;
+  int nx_send = 0, nx_recv = 0;
+  float nx_d = 0.0f;
+  int64_t nx_ep = 0;
+  auto prefetch_tile = [&](int t) {
+    if (t < a.ntiles) {
+      const int64_t e = static_cast<int64_t>(t) * TE + c;
+      const int64_t ec = e < a.M ? e : a.M - 1;
+      nx_ep = a.perm ? static_cast<int64_t>(a.perm[ec]) : ec;
+      nx_send = a.send[nx_ep];
+      nx_recv = a.recv[ec];
+      if constexpr (GAUSS) nx_d = a.edge_in[nx_ep];
+    }
+  };
+  prefetch_tile(tile_first);
+
   // ---- stage the pre-packed weights once per workgroup: a straight 16-byte copy into the LDS image ---------------
   {
     const float4* src = reinterpret_cast<const float4*>(a.packed);
@@ -110,24 +129,40 @@ __global__ __launch_bounds__(WAVES * 64) void cfconv_fused_kernel(CfconvArgs a) 
   __syncthreads();
 
   MP_STAMP(0)
-  float* T = Ts + wave * (F * T_LD);
+  float* T = Ts + wave * ((WAVES > 4 ? F / 2 : F) * T_LD);
   const float* w1_lane = W1s + (nk * hh) * F + 4 * c;  // + s*F           : rows s (lo half) / nk+s (hi half)
   const float* w2_lane = W2s + (4 * hh) * F + 4 * c;   // + (ib*32 + (r&3) + 8*(r>>2))*F
 
-  for (int tile0 = blockIdx.x * WAVES + wave; tile0 < a.ntiles; tile0 += gridDim.x * WAVES) {
+  for (int tile0 = tile_first; tile0 < a.ntiles; tile0 += tile_step) {
     const int tile = __builtin_amdgcn_readfirstlane(tile0);
     const int64_t e0 = static_cast<int64_t>(tile) * TE;
     const int64_t e_mine = e0 + c;
     const bool valid = e_mine < a.M;
-    const int64_t e_clamped = valid ? e_mine : a.M - 1;
-    const int64_t ep = a.perm ? static_cast<int64_t>(a.perm[e_clamped]) : e_clamped;
-    const int my_send = a.send[ep];
-    const int my_recv = a.recv[e_clamped];
+    const int64_t ep = nx_ep;
+    const int my_send = nx_send;
+    const int my_recv = nx_recv;
+    const float d_mine = nx_d;
+
+    // ---- sender rows of this tile: issued first, consumed after GEMM2 (coalesced 128-B reads per half wave) --------
+    float xv[4][16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int row = rowmap(r, hh);
+      const int snode = __shfl(my_send, row, 64);
+      const bool row_valid = (e0 + row) < a.M;
+      const float* xrow = a.x + static_cast<int64_t>(snode) * F + c;
+#pragma unroll
+      for (int jb = 0; jb < 4; ++jb) {
+        const float t = xrow[jb * 32];  // always in range: padding rows reuse the last valid edge's sender
+        xv[jb][r] = row_valid ? t : 0.0f;
+      }
+    }
+    prefetch_tile(tile0 + tile_step);  // next tile's edge data, in flight during this tile's GEMMs
 
     // ---- B operand of GEMM1: this lane's half of its edge's basis row (+ the constant 1 of the bias row) ----
     float rb[NKMAX];
     if constexpr (GAUSS) {
-      const float d = a.edge_in[ep];
+      const float d = d_mine;
       const float fbins = static_cast<float>(B);
 #pragma unroll
       for (int s = 0; s < NKMAX; ++s) {
@@ -176,21 +211,6 @@ __global__ __launch_bounds__(WAVES * 64) void cfconv_fused_kernel(CfconvArgs a) 
 #pragma unroll
       for (int r = 0; r < 16; ++r) h[ib][r] = FAST_SSP ? ssp_fast(h[ib][r]) : ssp_exact(h[ib][r]);
 
-    // ---- sender rows, issued now so that their latency hides under GEMM2 (coalesced 128-B reads per half wave) ---
-    float xv[4][16];
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int row = rowmap(r, hh);
-      const int snode = __shfl(my_send, row, 64);
-      const bool row_valid = (e0 + row) < a.M;
-      const float* xrow = a.x + static_cast<int64_t>(snode) * F + c;
-#pragma unroll
-      for (int jb = 0; jb < 4; ++jb) {
-        const float t = xrow[jb * 32];  // always in range: padding rows reuse the last valid edge's sender
-        xv[jb][r] = row_valid ? t : 0.0f;
-      }
-    }
-
     MP_STAMP(3)
     // ---- GEMM2: w[e][j] = sum_f h[e][f] W2[f][j] + b2[j]; A = the accumulator registers of GEMM1 ------------
     floatx16 w[4];
@@ -213,61 +233,70 @@ __global__ __launch_bounds__(WAVES * 64) void cfconv_fused_kernel(CfconvArgs a) 
     }
 
     MP_STAMP(4)
-    // ---- multiply by the sender row and transpose into the slab [feature][edge] ----------------------------------
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-#pragma unroll
-      for (int jb = 0; jb < 4; ++jb) {
-        const float4 m = make_float4(w[jb][4 * q] * xv[jb][4 * q], w[jb][4 * q + 1] * xv[jb][4 * q + 1],
-                                     w[jb][4 * q + 2] * xv[jb][4 * q + 2], w[jb][4 * q + 3] * xv[jb][4 * q + 3]);
-        *reinterpret_cast<float4*>(T + (jb * 32 + c) * T_LD + 8 * q + 4 * hh) = m;
-      }
-    }
-    MP_STAMP(5)
-    // the slab is private to this wave: LDS operations of one wave complete in order, no barrier needed
-    float va[TE], vb[TE];
-#pragma unroll
-    for (int q = 0; q < 8; ++q) {
-      const float4 ta = *reinterpret_cast<const float4*>(T + lane * T_LD + 4 * q);
-      const float4 tb = *reinterpret_cast<const float4*>(T + (64 + lane) * T_LD + 4 * q);
-      va[4 * q] = ta.x; va[4 * q + 1] = ta.y; va[4 * q + 2] = ta.z; va[4 * q + 3] = ta.w;
-      vb[4 * q] = tb.x; vb[4 * q + 1] = tb.y; vb[4 * q + 2] = tb.z; vb[4 * q + 3] = tb.w;
-    }
-
-    MP_STAMP(6)
-    // ---- in-order segmented sum over the 32 edges.  Segment starts come from one ballot (a scalar bit mask), the
-    //      receiver ids from v_readlane: no memory access and only scalar branches inside the walk.  Padding edges
-    //      of the last tile repeat the last receiver and carry zeros. ---------------------------------------------
+    // ---- multiply by the sender row, transpose through the slab [feature][edge] and sum the segments in edge order.
+    //      Segment starts come from one ballot (a scalar bit mask), receiver ids from v_readlane: no memory access and
+    //      only scalar branches inside the walk.  Padding edges of the last tile repeat the last receiver and carry
+    //      zeros.  With 8 waves per workgroup the slab holds 64 features and the epilogue runs in two passes. --------
     const int prev_recv = __shfl_up(my_recv, 1, 64);  // all lanes take part; lanes 0 / 32 are masked out below
     const unsigned start_mask =
         static_cast<unsigned>(__ballot((c > 0) & (my_recv != prev_recv)) & 0xffffffffull);
-    float sa = va[0], sb = vb[0];
-    bool first = true;
+    constexpr int NPASS = (WAVES > 4) ? 2 : 1;   // passes over the feature dimension
+    constexpr int JBP = 4 / NPASS;               // 32-wide feature blocks per pass
+    constexpr int NCOL = JBP / 2;                // features per lane per pass
 #pragma unroll
-    for (int i = 1; i < TE; ++i) {
-      if ((start_mask >> i) & 1u) {
-        const int cur = __builtin_amdgcn_readlane(my_recv, i - 1);
-        float* dst = a.out + static_cast<int64_t>(cur) * F + lane;
-        if (first) {
-          atomicAdd(dst, sa);
-          atomicAdd(dst + 64, sb);
-          first = false;
-        } else {
-          dst[0] = sa;
-          dst[64] = sb;
+    for (int pass = 0; pass < NPASS; ++pass) {
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+#pragma unroll
+        for (int jl = 0; jl < JBP; ++jl) {
+          const int jb = pass * JBP + jl;
+          const float4 m = make_float4(w[jb][4 * q] * xv[jb][4 * q], w[jb][4 * q + 1] * xv[jb][4 * q + 1],
+                                       w[jb][4 * q + 2] * xv[jb][4 * q + 2], w[jb][4 * q + 3] * xv[jb][4 * q + 3]);
+          *reinterpret_cast<float4*>(T + (jl * 32 + c) * T_LD + 8 * q + 4 * hh) = m;
         }
-        sa = va[i];
-        sb = vb[i];
-      } else {
-        sa += va[i];
-        sb += vb[i];
       }
-    }
-    {
-      const int cur = __builtin_amdgcn_readlane(my_recv, TE - 1);
-      float* dst = a.out + static_cast<int64_t>(cur) * F + lane;
-      atomicAdd(dst, sa);
-      atomicAdd(dst + 64, sb);
+      if (pass == 0) { MP_STAMP(5) }
+      // the slab is private to this wave: LDS operations of one wave complete in order, no barrier needed
+      float v[NCOL][TE];
+#pragma unroll
+      for (int k = 0; k < NCOL; ++k)
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+          const float4 t4 = *reinterpret_cast<const float4*>(T + (64 * k + lane) * T_LD + 4 * q);
+          v[k][4 * q] = t4.x; v[k][4 * q + 1] = t4.y; v[k][4 * q + 2] = t4.z; v[k][4 * q + 3] = t4.w;
+        }
+      if (pass == 0) { MP_STAMP(6) }
+      float acc[NCOL];
+#pragma unroll
+      for (int k = 0; k < NCOL; ++k) acc[k] = v[k][0];
+      bool first = true;
+      float* const out_lane = a.out + pass * (F / NPASS) + lane;
+#pragma unroll
+      for (int i = 1; i < TE; ++i) {
+        if ((start_mask >> i) & 1u) {
+          const int cur = __builtin_amdgcn_readlane(my_recv, i - 1);
+          float* dst = out_lane + static_cast<int64_t>(cur) * F;
+          if (first) {
+#pragma unroll
+            for (int k = 0; k < NCOL; ++k) atomicAdd(dst + 64 * k, acc[k]);
+            first = false;
+          } else {
+#pragma unroll
+            for (int k = 0; k < NCOL; ++k) dst[64 * k] = acc[k];
+          }
+#pragma unroll
+          for (int k = 0; k < NCOL; ++k) acc[k] = v[k][i];
+        } else {
+#pragma unroll
+          for (int k = 0; k < NCOL; ++k) acc[k] += v[k][i];
+        }
+      }
+      {
+        const int cur = __builtin_amdgcn_readlane(my_recv, TE - 1);
+        float* dst = out_lane + static_cast<int64_t>(cur) * F;
+#pragma unroll
+        for (int k = 0; k < NCOL; ++k) atomicAdd(dst + 64 * k, acc[k]);
+      }
     }
     MP_STAMP(7)
   }
@@ -306,7 +335,7 @@ __global__ void cfconv_pack_kernel(const float* __restrict__ W1, const float* __
 
 template <int WAVES>
 size_t cfconv_lds_bytes() {
-  return sizeof(float) * (MAX_KROWS * F + F * F + WAVES * F * T_LD);
+  return sizeof(float) * (MAX_KROWS * F + F * F + WAVES * (WAVES > 4 ? F / 2 : F) * T_LD);
 }
 
 template <int WAVES, bool GAUSS, bool FAST, int NKT, bool DIAG>
@@ -323,7 +352,11 @@ int launch_cfconv(const CfconvArgs& args, int grid, hipStream_t s) {
 }
 
 template <bool GAUSS, bool FAST>
-int launch_by_basis(const CfconvArgs& args, int grid, hipStream_t s) {
+int launch_by_basis(const CfconvArgs& args, int waves, int grid, hipStream_t s) {
+  if (waves == 8) {
+    if (args.B == 20) return launch_cfconv<8, GAUSS, FAST, 11, false>(args, grid, s);
+    return launch_cfconv<8, GAUSS, FAST, 0, false>(args, grid, s);
+  }
   if (args.B == 20) return launch_cfconv<4, GAUSS, FAST, 11, false>(args, grid, s);  // SchNet default: 20 bins
   return launch_cfconv<4, GAUSS, FAST, 0, false>(args, grid, s);
 }
@@ -337,15 +370,22 @@ int cfconv_dispatch(CfconvArgs args, bool gauss, int flags, hipStream_t s) {
   MP_REQUIRE(args.M < (int64_t{1} << 31), "mp_cfconv: M must fit int32");
   args.ntiles = static_cast<int>((args.M + TE - 1) / TE);
   const bool fast = (flags & 1) != 0;
-  // one workgroup per CU (LDS holds the weights); persistent over the tiles
-  int grid = (args.ntiles + 3) / 4;
+  // One workgroup per CU (the LDS holds the weights), persistent over the tiles; four waves = one per SIMD, each
+  // with a matrix pipe of its own.  An 8-wave build (two per SIMD, 256-VGPR cap, two-pass epilogue) exists behind
+  // flag bit 2; measured on MI355X it gains < 1 % at 2.5 M edges (the 4-wave kernel already keeps the pipe ~80 %
+  // busy at the clock the chip holds under this load) and loses at small M, so it is not selected automatically.
+  int waves = (flags & 4) ? 8 : 4;
+  int grid = (args.ntiles + waves - 1) / waves;
   if (grid > 256) grid = 256;
   if (args.diag) {
     MP_REQUIRE(gauss && args.B == 20, "mp_cfconv: the diagnostic build exists for the 20-bin Gauss variant only");
+    grid = (args.ntiles + 3) / 4 > 256 ? 256 : (args.ntiles + 3) / 4;
     return launch_cfconv<4, true, true, 11, true>(args, grid, s);
   }
-  if (gauss) return fast ? launch_by_basis<true, true>(args, grid, s) : launch_by_basis<true, false>(args, grid, s);
-  return fast ? launch_by_basis<false, true>(args, grid, s) : launch_by_basis<false, false>(args, grid, s);
+  if (gauss) {
+    return fast ? launch_by_basis<true, true>(args, waves, grid, s) : launch_by_basis<true, false>(args, waves, grid, s);
+  }
+  return fast ? launch_by_basis<false, true>(args, waves, grid, s) : launch_by_basis<false, false>(args, waves, grid, s);
 }
 
 }  // namespace

@@ -93,8 +93,14 @@ __global__ void edge_prepare_kernel(const int64_t* __restrict__ idx, int64_t M, 
                                     int32_t* __restrict__ flags) {
   const int64_t stride = static_cast<int64_t>(gridDim.x) * blockDim.x;
   int local_flags = 0;
-  for (int64_t e = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x; e < M; e += stride) {
-    const int64_t g = owner_of(edge_splits, G, e);
+  for (int64_t e = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x; e - (threadIdx.x & 63) < M;
+       e += stride) {
+    // The graph of the wave's first edge comes from a wave-uniform binary search (scalar loads, one per step for
+    // the whole wave); each lane then walks forward the few graphs its own edge may be ahead.
+    const int64_t e_wave = __builtin_amdgcn_readfirstlane(static_cast<int>(e - (threadIdx.x & 63)));
+    int64_t g = owner_of(edge_splits, G, e_wave < M ? e_wave : M - 1);
+    if (e >= M) continue;
+    while (g + 1 < G && edge_splits[g + 1] <= e) ++g;
     const int64_t base = node_splits[g];
     const int64_t n_g = node_splits[g + 1] - base;
     const longlong2 v = reinterpret_cast<const longlong2*>(idx)[e];
@@ -111,9 +117,10 @@ __global__ void edge_prepare_kernel(const int64_t* __restrict__ idx, int64_t M, 
     recv[e] = static_cast<int32_t>(si);
     send[e] = static_cast<int32_t>(sj);
     if (e > 0) {
-      int64_t base_prev = base;
-      if (edge_splits[g] > e - 1) base_prev = node_splits[owner_of(edge_splits, G, e - 1)];
-      if (idx[(e - 1) * 2] + base_prev > si) local_flags |= MP_FLAG_UNSORTED_COL0;
+      // receiver of the previous edge: same graph unless this edge opens its graph (then any earlier graph's ids
+      // are smaller, because node offsets grow with the graph index)
+      const bool same_graph = edge_splits[g] < e;
+      if (same_graph && idx[(e - 1) * 2] + base > si) local_flags |= MP_FLAG_UNSORTED_COL0;
     }
     if (dist) {
       const float dx = xyz[si * 3 + 0] - xyz[sj * 3 + 0];

@@ -20,7 +20,6 @@ namespace {
 using floatx4 = __attribute__((ext_vector_type(4))) float;
 
 constexpr int F = 128;
-constexpr int TN = 16;     // nodes per tile
 constexpr int X_LD = 130;  // padded row stride of the LDS activation tiles: (2*node + k) mod 32 is conflict-free
 
 __device__ __forceinline__ float ssp_exact(float x) { return mp_softplus(x) - 0.6931471805599453f; }
@@ -36,16 +35,22 @@ __device__ __forceinline__ void load_wslice(const float* __restrict__ W, int U, 
     for (int s = 0; s < K / 4; ++s) wr[cb][s] = W[(4 * s + g) * U + col0 + 16 * cb + cc];
 }
 
-// acc[cb] += Xs(16 x K) @ Wslice ; A operand from LDS: lane supplies Xs[node = lane&15][k = 4s + (lane>>4)].
-template <int K, int NCB>
+// acc[rb][cb] += Xs(16*RB x K) @ Wslice ; A operand from LDS: lane supplies Xs[node = 16 rb + (lane&15)][k = 4s + (lane>>4)];
+// every weight register feeds RB MFMAs.
+template <int K, int NCB, int RB>
 __device__ __forceinline__ void gemm_tile(const float* __restrict__ Xs, int lane, const float (&wr)[NCB][K / 4],
-                                          floatx4 (&acc)[NCB]) {
+                                          floatx4 (&acc)[RB][NCB]) {
   const float* xp = Xs + (lane & 15) * X_LD + (lane >> 4);
 #pragma unroll
   for (int s = 0; s < K / 4; ++s) {
-    const float av = xp[4 * s];
+    float av[RB];
 #pragma unroll
-    for (int cb = 0; cb < NCB; ++cb) acc[cb] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, wr[cb][s], acc[cb], 0, 0, 0);
+    for (int rb = 0; rb < RB; ++rb) av[rb] = xp[rb * 16 * X_LD + 4 * s];
+#pragma unroll
+    for (int rb = 0; rb < RB; ++rb)
+#pragma unroll
+      for (int cb = 0; cb < NCB; ++cb)
+        acc[rb][cb] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[rb], wr[cb][s], acc[rb][cb], 0, 0, 0);
   }
 }
 
@@ -79,17 +84,20 @@ struct NodeArgs {
 enum NodeMode { NODE_IN = 0, NODE_MID = 1, NODE_LAST = 2 };
 
 // Epilogue helper: visit the wave's output elements.  C layout of 16x16x4: col = lane&15, row = 4*(lane>>4) + r.
-#define MP_FOR_OUT(cb, r, row, col, body)                           \
-  _Pragma("unroll") for (int cb = 0; cb < 2; ++cb) {                \
-    _Pragma("unroll") for (int r = 0; r < 4; ++r) {                 \
-      const int row = 4 * (lane >> 4) + r;                          \
-      const int col = wave * 32 + 16 * cb + (lane & 15);            \
-      body                                                          \
-    }                                                               \
+#define MP_FOR_OUT(cb, r, row, col, body)                             \
+  _Pragma("unroll") for (int rb = 0; rb < RB; ++rb) {                 \
+    _Pragma("unroll") for (int cb = 0; cb < 2; ++cb) {                \
+      _Pragma("unroll") for (int r = 0; r < 4; ++r) {                 \
+        const int row = 16 * rb + 4 * (lane >> 4) + r;                \
+        const int col = wave * 32 + 16 * cb + (lane & 15);            \
+        body                                                          \
+      }                                                               \
+    }                                                                 \
   }
 
-template <int MODE, int E>
+template <int MODE, int E, int RB>
 __global__ __launch_bounds__(256) void schnet_node_kernel(NodeArgs a) {
+  constexpr int TN = 16 * RB;  // nodes per tile
   __shared__ float Xa[TN * X_LD];
   __shared__ float Xb[TN * X_LD];
   const int tid = threadIdx.x;
@@ -160,13 +168,15 @@ __global__ __launch_bounds__(256) void schnet_node_kernel(NodeArgs a) {
     }
     __syncthreads();
 
-    floatx4 acc[2];
+    floatx4 acc[RB][2];
     // ---- GEMM 1: IN: n = emb @ W0 + b0 ; MID/LAST: t = ssp(agg @ W2 + b2) ---------------------------------------
-#pragma unroll
-    for (int cb = 0; cb < 2; ++cb) acc[cb] = floatx4{0.f, 0.f, 0.f, 0.f};
-    gemm_tile<(MODE == NODE_IN ? E : F), 2>(Xa, lane, w_first, acc);
+#define MP_ZERO_ACC                                              \
+  _Pragma("unroll") for (int rb = 0; rb < RB; ++rb)              \
+      _Pragma("unroll") for (int cb = 0; cb < 2; ++cb) acc[rb][cb] = floatx4{0.f, 0.f, 0.f, 0.f};
+    MP_ZERO_ACC
+    gemm_tile<(MODE == NODE_IN ? E : F), 2, RB>(Xa, lane, w_first, acc);
     MP_FOR_OUT(cb, r, row, col, {
-      float v = acc[cb][r] + bias_first[cb];
+      float v = acc[rb][cb][r] + bias_first[cb];
       if constexpr (MODE != NODE_IN) v = ssp_exact(v);
       Xb[row * X_LD + col] = v;
       if constexpr (MODE == NODE_IN) {
@@ -176,17 +186,16 @@ __global__ __launch_bounds__(256) void schnet_node_kernel(NodeArgs a) {
     __syncthreads();
 
     // ---- GEMM 2: IN: x = n @ Wx ; MID/LAST: n += t @ W3 + b3 ----------------------------------------------------
-#pragma unroll
-    for (int cb = 0; cb < 2; ++cb) acc[cb] = floatx4{0.f, 0.f, 0.f, 0.f};
-    gemm_tile<F, 2>(Xb, lane, w_second, acc);
+    MP_ZERO_ACC
+    gemm_tile<F, 2, RB>(Xb, lane, w_second, acc);
     if constexpr (MODE == NODE_IN) {
       MP_FOR_OUT(cb, r, row, col, {
-        if (node0 + row < a.N) a.x[(node0 + row) * F + col] = acc[cb][r];
+        if (node0 + row < a.N) a.x[(node0 + row) * F + col] = acc[rb][cb][r];
       })
     } else {
       MP_FOR_OUT(cb, r, row, col, {
         const bool ok = node0 + row < a.N;
-        const float y = acc[cb][r] + bias_second[cb];
+        const float y = acc[rb][cb][r] + bias_second[cb];
         const float nv = ok ? a.n[(node0 + row) * F + col] : 0.0f;
         const float nn = nv + y;  // LazyAdd([node, x])
         if (ok && MODE == NODE_MID) a.n[(node0 + row) * F + col] = nn;
@@ -195,26 +204,28 @@ __global__ __launch_bounds__(256) void schnet_node_kernel(NodeArgs a) {
       __syncthreads();
 
       // ---- GEMM 3: MID: x = n @ Wx ; LAST: u = ssp(n @ Wl0 + bl0) ----------------------------------------------
-#pragma unroll
-      for (int cb = 0; cb < 2; ++cb) acc[cb] = floatx4{0.f, 0.f, 0.f, 0.f};
-      gemm_tile<F, 2>(Xa, lane, w_third, acc);
+      MP_ZERO_ACC
+      gemm_tile<F, 2, RB>(Xa, lane, w_third, acc);
       if constexpr (MODE == NODE_MID) {
         MP_FOR_OUT(cb, r, row, col, {
-          if (node0 + row < a.N) a.x[(node0 + row) * F + col] = acc[cb][r];
+          if (node0 + row < a.N) a.x[(node0 + row) * F + col] = acc[rb][cb][r];
         })
       } else {
-        MP_FOR_OUT(cb, r, row, col, { Xb[row * X_LD + col] = ssp_exact(acc[cb][r] + bias_third[cb]); })
+        MP_FOR_OUT(cb, r, row, col, { Xb[row * X_LD + col] = ssp_exact(acc[rb][cb][r] + bias_third[cb]); })
         __syncthreads();
         // ---- GEMM 4 (LAST): h = ssp(u @ Wl1 + bl1), 64 output columns = 16 per wave ------------------------------
-        floatx4 acc4[1];
-        acc4[0] = floatx4{0.f, 0.f, 0.f, 0.f};
-        gemm_tile<F, 1>(Xb, lane, w_fourth, acc4);
+        floatx4 acc4[RB][1];
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const int row = 4 * (lane >> 4) + r;
-          const int col = wave * 16 + (lane & 15);
-          if (node0 + row < a.N) a.h[(node0 + row) * 64 + col] = ssp_exact(acc4[0][r] + bias_fourth);
-        }
+        for (int rb = 0; rb < RB; ++rb) acc4[rb][0] = floatx4{0.f, 0.f, 0.f, 0.f};
+        gemm_tile<F, 1, RB>(Xb, lane, w_fourth, acc4);
+#pragma unroll
+        for (int rb = 0; rb < RB; ++rb)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const int row = 16 * rb + 4 * (lane >> 4) + r;
+            const int col = wave * 16 + (lane & 15);
+            if (node0 + row < a.N) a.h[(node0 + row) * 64 + col] = ssp_exact(acc4[rb][0][r] + bias_fourth);
+          }
       }
     }
     __syncthreads();  // Xa / Xb are reused by the next tile
@@ -222,31 +233,54 @@ __global__ __launch_bounds__(256) void schnet_node_kernel(NodeArgs a) {
 }
 
 // Readout: PoolingNodes(sum) over each graph's rows of h (N,64), then MLP([64,1], [ssp, linear]).
-// One wave per graph, lane = feature; sequential node order (the order tf.math.segment_sum uses).
-__global__ void schnet_readout_kernel(const float* __restrict__ h, const int64_t* __restrict__ splits, int64_t G,
-                                      const float* __restrict__ Wo0, const float* __restrict__ bo0,
-                                      const float* __restrict__ Wo1, const float* __restrict__ bo1,
-                                      float* __restrict__ out) {
+// One wave per graph, lane = feature; sequential node order (the order tf.math.segment_sum uses).  The 64x64 weight
+// matrix is staged once per workgroup in LDS; the pooled vector is broadcast with v_readlane (scalar operand of the
+// fma), so the 64-step dot product touches neither memory nor the LDS crossbar for its left operand.
+__global__ __launch_bounds__(256) void schnet_readout_kernel(const float* __restrict__ h,
+                                                             const int64_t* __restrict__ splits, int64_t G,
+                                                             const float* __restrict__ Wo0,
+                                                             const float* __restrict__ bo0,
+                                                             const float* __restrict__ Wo1,
+                                                             const float* __restrict__ bo1, float* __restrict__ out) {
+  __shared__ float Ws[64 * 64];
+  for (int i = threadIdx.x; i < 64 * 64 / 4; i += 256)
+    reinterpret_cast<float4*>(Ws)[i] = reinterpret_cast<const float4*>(Wo0)[i];
   const int lane = threadIdx.x & 63;
+  const float b0v = bo0 ? bo0[lane] : 0.0f;
+  const float w1v = Wo1[lane];
+  const float b1v = bo1 ? bo1[0] : 0.0f;
+  __syncthreads();
   const int64_t wave_global = (static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x) >> 6;
   const int64_t nwaves = (static_cast<int64_t>(gridDim.x) * blockDim.x) >> 6;
   for (int64_t g = wave_global; g < G; g += nwaves) {
     float pooled = 0.0f;
-    for (int64_t nidx = splits[g]; nidx < splits[g + 1]; ++nidx) pooled += h[nidx * 64 + lane];
+    const int64_t lo = splits[g], hi = splits[g + 1];
+    for (int64_t nidx = lo; nidx < hi; ++nidx) pooled += h[nidx * 64 + lane];
     float y = 0.0f;
-#pragma unroll 8
-    for (int k = 0; k < 64; ++k) y = fmaf(__shfl(pooled, k, 64), Wo0[k * 64 + lane], y);
-    y = ssp_exact(y + (bo0 ? bo0[lane] : 0.0f));
-    float o = y * Wo1[lane];
+#pragma unroll
+    for (int k = 0; k < 64; ++k) y = fmaf(__int_as_float(__builtin_amdgcn_readlane(__float_as_int(pooled), k)), Ws[k * 64 + lane], y);
+    y = ssp_exact(y + b0v);
+    float o = y * w1v;
     for (int off = 32; off > 0; off >>= 1) o += __shfl_xor(o, off, 64);
-    if (lane == 0) out[g] = o + (bo1 ? bo1[0] : 0.0f);
+    if (lane == 0) out[g] = o + b1v;
   }
 }
 
+// Small batches (every 16-node tile gets a workgroup of its own on the 256 CUs) are latency bound: 16-node tiles.
+// Large batches are throughput bound: 64-node tiles (each weight register feeds 4 MFMAs, 4x fewer barriers per node)
+// and two workgroups per CU so that one tile's barriers / epilogue hide under the other's MFMAs.
 template <int MODE, int E>
-int launch_node(const NodeArgs& a, hipStream_t s, const char* what) {
-  int grid = a.ntiles < 256 ? a.ntiles : 256;
-  schnet_node_kernel<MODE, E><<<grid, 256, 0, s>>>(a);
+int launch_node(NodeArgs a, hipStream_t s, const char* what) {
+  const int64_t tiles16 = (a.N + 15) / 16;
+  if (tiles16 <= 1024) {
+    a.ntiles = static_cast<int>(tiles16);
+    const int grid = a.ntiles < 512 ? a.ntiles : 512;
+    schnet_node_kernel<MODE, E, 1><<<grid, 256, 0, s>>>(a);
+  } else {
+    a.ntiles = static_cast<int>((a.N + 63) / 64);
+    const int grid = a.ntiles < 512 ? a.ntiles : 512;
+    schnet_node_kernel<MODE, E, 4><<<grid, 256, 0, s>>>(a);
+  }
   return mp::check_launch(what);
 }
 
@@ -261,7 +295,7 @@ int mp_schnet_node_in_f32(const float* numbers, int64_t N, const float* emb, int
   if (N == 0) return MP_OK;
   MP_REQUIRE(numbers && emb && W0 && Wx && n_out && x_out, "mp_schnet_node_in_f32: null pointer");
   NodeArgs a{};
-  a.N = N; a.ntiles = static_cast<int>((N + TN - 1) / TN);
+  a.N = N;
   a.numbers = numbers; a.emb = emb; a.vocab = vocab; a.W0 = W0; a.b0 = b0; a.Wx = Wx; a.n = n_out; a.x = x_out;
   return launch_node<NODE_IN, 64>(a, mp::as_stream(stream), "mp_schnet_node_in_f32");
 }
@@ -272,7 +306,7 @@ int mp_schnet_node_update_f32(float* agg, int64_t N, const float* W2, const floa
   if (N == 0) return MP_OK;
   MP_REQUIRE(agg && W2 && W3 && n_inout && Wx_next && x_out, "mp_schnet_node_update_f32: null pointer");
   NodeArgs a{};
-  a.N = N; a.ntiles = static_cast<int>((N + TN - 1) / TN);
+  a.N = N;
   a.agg = agg; a.W2 = W2; a.b2 = b2; a.W3 = W3; a.b3 = b3; a.n = n_inout; a.Wx = Wx_next; a.x = x_out;
   return launch_node<NODE_MID, 64>(a, mp::as_stream(stream), "mp_schnet_node_update_f32");
 }
@@ -284,7 +318,7 @@ int mp_schnet_node_last_f32(float* agg, int64_t N, const float* W2, const float*
   if (N == 0) return MP_OK;
   MP_REQUIRE(agg && W2 && W3 && n_in && Wl0 && Wl1 && h_out, "mp_schnet_node_last_f32: null pointer");
   NodeArgs a{};
-  a.N = N; a.ntiles = static_cast<int>((N + TN - 1) / TN);
+  a.N = N;
   a.agg = agg; a.W2 = W2; a.b2 = b2; a.W3 = W3; a.b3 = b3; a.n = const_cast<float*>(n_in);
   a.Wl0 = Wl0; a.bl0 = bl0; a.Wl1 = Wl1; a.bl1 = bl1; a.h = h_out;
   return launch_node<NODE_LAST, 64>(a, mp::as_stream(stream), "mp_schnet_node_last_f32");
@@ -295,7 +329,8 @@ int mp_schnet_readout_f32(const float* h, const int64_t* node_splits, int64_t G,
   MP_REQUIRE(G >= 0, "mp_schnet_readout_f32: bad sizes");
   if (G == 0) return MP_OK;
   MP_REQUIRE(h && node_splits && Wo0 && Wo1 && out, "mp_schnet_readout_f32: null pointer");
-  schnet_readout_kernel<<<mp::grid_for(G * 64), 256, 0, mp::as_stream(stream)>>>(h, node_splits, G, Wo0, bo0, Wo1,
+  schnet_readout_kernel<<<static_cast<unsigned>(mp::ceil_div(G, 4) < 1024 ? mp::ceil_div(G, 4) : 1024), 256, 0,
+                          mp::as_stream(stream)>>>(h, node_splits, G, Wo0, bo0, Wo1,
                                                                                   bo1, out);
   return mp::check_launch("mp_schnet_readout_f32");
 }

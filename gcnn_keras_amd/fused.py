@@ -30,12 +30,12 @@ def supports(config):
 
 
 class FusedSchnet:
-    def __init__(self, params, depth=3, gauss_args=None, fast_softplus=True, use_graph=True):
+    def __init__(self, params, depth=3, gauss_args=None, fast_softplus=True, use_graph=True, cfconv_flags=0):
         if not torch.cuda.is_available():
             raise _ffi.EngineError("FusedSchnet needs an MI355X (no CPU fallback)")
         self.depth = depth
         self.gauss = dict(gauss_args or {"bins": 20, "distance": 4, "offset": 0.0, "sigma": 0.4})
-        self.flags_arg = 1 if fast_softplus else 0
+        self.flags_arg = (1 if fast_softplus else 0) | int(cfconv_flags)
         self.use_graph = use_graph
         self.p = {k: torch.from_numpy(np.ascontiguousarray(v, dtype=np.float32)).cuda() for k, v in params.items()}
         if tuple(self.p["embedding"].shape)[1] != 64 or tuple(self.p["dense0/kernel"].shape) != (64, 128):

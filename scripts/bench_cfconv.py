@@ -6,11 +6,11 @@ from gcnn_keras_amd import _ffi, synth
 from gcnn_keras_amd.engine import _HipTimer
 from gcnn_keras_amd.fused import FusedSchnet
 
-def run(graphs, flags_list=(0, 1), iters=30):
+def run(graphs, flags_list=(1, 3, 5), iters=30):
     b = synth.qm9_like_batch(num_graphs=graphs, seed=1234)
     p = synth.schnet_params(seed=7)
     for fl in flags_list:
-        f = FusedSchnet(p, depth=3, fast_softplus=bool(fl))
+        f = FusedSchnet(p, depth=3, fast_softplus=bool(fl & 1), cfconv_flags=fl & 6)
         dev = {"z": torch.from_numpy(b["node_number"]).cuda(), "xyz": torch.from_numpy(b["node_coordinates"]).cuda(),
                "idx": torch.from_numpy(b["edge_indices"]).cuda(), "ns": torch.from_numpy(b["node_splits"]).cuda(),
                "es": torch.from_numpy(b["edge_splits"]).cuda(), "ns_host": b["node_splits"], "es_host": b["edge_splits"]}
@@ -20,7 +20,7 @@ def run(graphs, flags_list=(0, 1), iters=30):
         r = f.roofline(8000.0, 157.3, iters)
         with torch.cuda.stream(f.stream):
             ms_fwd = _HipTimer().time_ms(lambda: _ffi.call("mp_graph_launch", f.graph, _ffi.stream()), iters)
-        print("graphs=%d N=%d M=%d fast=%d cfconv %.1f us  %.1f TF (%.1f%%)  forward %.1f us  %.1f Medges/s" % (
+        print("graphs=%d N=%d M=%d flags=%d cfconv %.1f us  %.1f TF (%.1f%%)  forward %.1f us  %.1f Medges/s" % (
             graphs, n, m, fl, r["avg_launch_us"], r["achieved"], 100 * r["frac"], ms_fwd * 1e3, m / ms_fwd / 1e3))
 
 if __name__ == "__main__":
@@ -41,10 +41,17 @@ def diag(graphs):
     f.forward(); torch.cuda.synchronize()
     d = torch.zeros(8, dtype=torch.int64, device="cuda")
     scratch = torch.zeros_like(f.agg)
-    _ffi.call("mp_cfconv_gauss_diag_f32", _ffi.ptr(f.x), n, _ffi.ptr(f.dist), 20, 4.0, 0.4, 0.0,
-              _ffi.ptr(f.packed[0]), _ffi.ptr(f.recv), _ffi.ptr(f.send), None, m, _ffi.ptr(scratch),
-              _ffi.ptr(d), _ffi.stream())
+    def launch():
+        _ffi.call("mp_cfconv_gauss_diag_f32", _ffi.ptr(f.x), n, _ffi.ptr(f.dist), 20, 4.0, 0.4, 0.0,
+                  _ffi.ptr(f.packed[0]), _ffi.ptr(f.recv), _ffi.ptr(f.send), None, m, _ffi.ptr(scratch),
+                  _ffi.ptr(d), _ffi.stream())
+    ms = _HipTimer().time_ms(launch, 10)
+    d.zero_()
+    launch()
     torch.cuda.synchronize()
+    waves = min(256, ((m + 31) // 32 + 3) // 4) * 4
+    cyc = d.cpu().numpy().astype(np.float64).sum() / waves
+    print("diag kernel %.1f us, %.0f shader cycles per wave -> clock %.2f GHz" % (ms * 1e3, cyc, cyc / (ms * 1e3) / 1e3))
     v = d.cpu().numpy().astype(np.float64)
     names = ["stage", "setup+gauss", "gemm1", "ssp+xload", "gemm2", "mul+Twrite", "Tread", "walk+flush"]
     ntiles = (m + 31) // 32

@@ -36,7 +36,7 @@ def _cfconv_case(seed, num_graphs=9, shuffle=False):
 
 @pytest.mark.parametrize("shuffle", [False, True])
 @pytest.mark.parametrize("variant", ["rbf", "gauss"])
-@pytest.mark.parametrize("fast", [0, 1])
+@pytest.mark.parametrize("fast", [0, 1, 4, 5])   # bit0: fast softplus, bit2: force the 8-wave workgroup variant
 def test_cfconv_fused_vs_oracle(shuffle, variant, fast):
     from gcnn_keras_amd import _ffi
     from gcnn_keras_amd.ragged import RaggedTensor
