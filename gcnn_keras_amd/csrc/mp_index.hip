@@ -86,23 +86,58 @@ __global__ void csr_from_sorted_kernel(const int32_t* __restrict__ seg, int64_t 
 // index_prepare (K = 2) fused with the geometry pre-step NodePosition -> LazySubtract -> EuclideanNorm
 // (kgcnn/literature/Schnet.py:116-117): one pass over the (M,2) int64 rows yields receiver / sender ids and the
 // edge distance the Gauss expansion starts from.
-__global__ void edge_prepare_kernel(const int64_t* __restrict__ idx, int64_t M, const int64_t* __restrict__ node_splits,
-                                    const int64_t* __restrict__ edge_splits, int64_t G, int64_t N,
-                                    const float* __restrict__ xyz, int32_t* __restrict__ recv,
-                                    int32_t* __restrict__ send, float* __restrict__ dist,
-                                    int32_t* __restrict__ flags) {
+// owner search on a staged (LDS) copy of the splits
+__device__ __forceinline__ int owner_of_lds(const int64_t* splits, int G, int64_t e) {
+  int lo = 0, hi = G;
+  while (hi - lo > 1) {
+    const int mid = (lo + hi) >> 1;
+    if (splits[mid] <= e) lo = mid; else hi = mid;
+  }
+  return lo;
+}
+
+constexpr int PREP_LDS_GRAPHS = 1023;  // batches up to this many graphs search their row_splits in LDS
+
+// LDS_SPLITS: every workgroup first copies both row_splits arrays (G+1 <= 1024 entries each) into LDS with one
+// coalesced round trip; the per-edge owner search then never leaves the CU.  At QM9 batch sizes this kernel is a chain
+// of dependent round trips (search steps -> offsets -> index row -> coordinates), so removing the ~7 search trips is
+// what matters.  Larger batches search the L2-resident arrays directly (one wave-uniform search + a short walk).
+template <bool LDS_SPLITS>
+__global__ __launch_bounds__(256) void edge_prepare_kernel(const int64_t* __restrict__ idx, int64_t M,
+                                                           const int64_t* __restrict__ node_splits,
+                                                           const int64_t* __restrict__ edge_splits, int64_t G,
+                                                           int64_t N, const float* __restrict__ xyz,
+                                                           int32_t* __restrict__ recv, int32_t* __restrict__ send,
+                                                           float* __restrict__ dist, int32_t* __restrict__ flags) {
+  __shared__ int64_t s_es[LDS_SPLITS ? PREP_LDS_GRAPHS + 1 : 1];
+  __shared__ int64_t s_ns[LDS_SPLITS ? PREP_LDS_GRAPHS + 1 : 1];
+  if constexpr (LDS_SPLITS) {
+    for (int i = threadIdx.x; i <= G; i += blockDim.x) {
+      s_es[i] = edge_splits[i];
+      s_ns[i] = node_splits[i];
+    }
+    __syncthreads();
+  }
   const int64_t stride = static_cast<int64_t>(gridDim.x) * blockDim.x;
   int local_flags = 0;
   for (int64_t e = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x; e - (threadIdx.x & 63) < M;
        e += stride) {
-    // The graph of the wave's first edge comes from a wave-uniform binary search (scalar loads, one per step for
-    // the whole wave); each lane then walks forward the few graphs its own edge may be ahead.
-    const int64_t e_wave = __builtin_amdgcn_readfirstlane(static_cast<int>(e - (threadIdx.x & 63)));
-    int64_t g = owner_of(edge_splits, G, e_wave < M ? e_wave : M - 1);
-    if (e >= M) continue;
-    while (g + 1 < G && edge_splits[g + 1] <= e) ++g;
-    const int64_t base = node_splits[g];
-    const int64_t n_g = node_splits[g + 1] - base;
+    int64_t g, base, n_g, g_start;
+    if constexpr (LDS_SPLITS) {
+      if (e >= M) continue;
+      g = owner_of_lds(s_es, static_cast<int>(G), e);
+      base = s_ns[g];
+      n_g = s_ns[g + 1] - base;
+      g_start = s_es[g];
+    } else {
+      const int64_t e_wave = __builtin_amdgcn_readfirstlane(static_cast<int>(e - (threadIdx.x & 63)));
+      g = owner_of(edge_splits, G, e_wave < M ? e_wave : M - 1);
+      if (e >= M) continue;
+      while (g + 1 < G && edge_splits[g + 1] <= e) ++g;
+      base = node_splits[g];
+      n_g = node_splits[g + 1] - base;
+      g_start = edge_splits[g];
+    }
     const longlong2 v = reinterpret_cast<const longlong2*>(idx)[e];
     int64_t i = v.x, j = v.y;
     if (i < 0 || i >= n_g || j < 0 || j >= n_g) {
@@ -116,12 +151,9 @@ __global__ void edge_prepare_kernel(const int64_t* __restrict__ idx, int64_t M, 
     if (sj >= N) sj = N > 0 ? N - 1 : 0;
     recv[e] = static_cast<int32_t>(si);
     send[e] = static_cast<int32_t>(sj);
-    if (e > 0) {
-      // receiver of the previous edge: same graph unless this edge opens its graph (then any earlier graph's ids
-      // are smaller, because node offsets grow with the graph index)
-      const bool same_graph = edge_splits[g] < e;
-      if (same_graph && idx[(e - 1) * 2] + base > si) local_flags |= MP_FLAG_UNSORTED_COL0;
-    }
+    // receiver of the previous edge: only the same graph can break the order (an earlier graph's ids are smaller
+    // because node offsets grow with the graph index)
+    if (g_start < e && idx[(e - 1) * 2] + base > si) local_flags |= MP_FLAG_UNSORTED_COL0;
     if (dist) {
       const float dx = xyz[si * 3 + 0] - xyz[sj * 3 + 0];
       const float dy = xyz[si * 3 + 1] - xyz[sj * 3 + 1];
@@ -177,8 +209,13 @@ int mp_edge_prepare_i64_f32(const int64_t* idx, int64_t M, const int64_t* node_s
   MP_REQUIRE((dist == nullptr) || (xyz != nullptr), "mp_edge_prepare_i64_f32: dist requested without coordinates");
   if (M == 0) return MP_OK;
   MP_REQUIRE(idx && recv && send && node_splits && edge_splits && G > 0, "mp_edge_prepare_i64_f32: null pointer");
-  edge_prepare_kernel<<<mp::grid_for(M), 256, 0, mp::as_stream(stream)>>>(idx, M, node_splits, edge_splits, G, N, xyz,
-                                                                           recv, send, dist, flags);
+  if (G <= PREP_LDS_GRAPHS) {
+    edge_prepare_kernel<true><<<mp::grid_for(M), 256, 0, mp::as_stream(stream)>>>(idx, M, node_splits, edge_splits, G, N,
+                                                                                   xyz, recv, send, dist, flags);
+  } else {
+    edge_prepare_kernel<false><<<mp::grid_for(M), 256, 0, mp::as_stream(stream)>>>(idx, M, node_splits, edge_splits, G,
+                                                                                    N, xyz, recv, send, dist, flags);
+  }
   return mp::check_launch("mp_edge_prepare_i64_f32");
 }
 

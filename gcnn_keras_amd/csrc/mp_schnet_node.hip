@@ -169,6 +169,13 @@ __global__ __launch_bounds__(256) void schnet_node_kernel(NodeArgs a) {
     __syncthreads();
 
     floatx4 acc[RB][2];
+    // residual rows of n, requested now so that the round trip hides under GEMM 1 and 2
+    float n_res[RB][2][4];
+    if constexpr (MODE != NODE_IN) {
+      MP_FOR_OUT(cb, r, row, col, {
+        n_res[rb][cb][r] = (node0 + row < a.N) ? a.n[(node0 + row) * F + col] : 0.0f;
+      })
+    }
     // ---- GEMM 1: IN: n = emb @ W0 + b0 ; MID/LAST: t = ssp(agg @ W2 + b2) ---------------------------------------
 #define MP_ZERO_ACC                                              \
   _Pragma("unroll") for (int rb = 0; rb < RB; ++rb)              \
@@ -196,7 +203,7 @@ __global__ __launch_bounds__(256) void schnet_node_kernel(NodeArgs a) {
       MP_FOR_OUT(cb, r, row, col, {
         const bool ok = node0 + row < a.N;
         const float y = acc[rb][cb][r] + bias_second[cb];
-        const float nv = ok ? a.n[(node0 + row) * F + col] : 0.0f;
+        const float nv = n_res[rb][cb][r];
         const float nn = nv + y;  // LazyAdd([node, x])
         if (ok && MODE == NODE_MID) a.n[(node0 + row) * F + col] = nn;
         Xa[row * X_LD + col] = nn;
@@ -255,7 +262,15 @@ __global__ __launch_bounds__(256) void schnet_readout_kernel(const float* __rest
   for (int64_t g = wave_global; g < G; g += nwaves) {
     float pooled = 0.0f;
     const int64_t lo = splits[g], hi = splits[g + 1];
-    for (int64_t nidx = lo; nidx < hi; ++nidx) pooled += h[nidx * 64 + lane];
+    // eight independent row loads in flight per step (a dependent one-row-at-a-time loop pays one L2 round trip per
+    // node); the adds stay in node order
+    for (int64_t base = lo; base < hi; base += 8) {
+      float v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) v[u] = (base + u < hi) ? h[(base + u) * 64 + lane] : 0.0f;
+#pragma unroll
+      for (int u = 0; u < 8; ++u) pooled += (base + u < hi) ? v[u] : 0.0f;
+    }
     float y = 0.0f;
 #pragma unroll
     for (int k = 0; k < 64; ++k) y = fmaf(__int_as_float(__builtin_amdgcn_readlane(__float_as_int(pooled), k)), Ws[k * 64 + lane], y);

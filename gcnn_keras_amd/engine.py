@@ -104,6 +104,11 @@ class SchnetForward:
         self.num_launches = _ffi.launch_count() - before
         return out
 
+    @property
+    def stream(self):
+        """The HIP stream the forward is replayed on (run the step loop under ``torch.cuda.stream(fwd.stream)``)."""
+        return self._fused.stream if self._fused is not None else torch.cuda.current_stream()
+
     def check_flags(self):
         if self._fused is not None:
             self._fused.check_flags()

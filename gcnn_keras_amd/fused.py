@@ -141,7 +141,9 @@ class FusedSchnet:
     def forward(self):
         """One forward of the bound batch; returns the (G', 1) prediction tensor (valid after stream sync)."""
         cur = torch.cuda.current_stream()
-        self.stream.wait_stream(cur)
+        same = cur == self.stream  # callers that already run on the engine's stream pay no cross-stream events
+        if not same:
+            self.stream.wait_stream(cur)
         with torch.cuda.stream(self.stream):
             if not self.use_graph:
                 self._launch_all()
@@ -157,7 +159,8 @@ class FusedSchnet:
                         _ffi.call("mp_graph_end", _ffi.stream(), ctypes.byref(exe))
                     self.graph = exe
                 _ffi.call("mp_graph_launch", self.graph, _ffi.stream())
-        cur.wait_stream(self.stream)
+        if not same:
+            cur.wait_stream(self.stream)
         return self.out if self.out_rows == self.G else self.out[:self.out_rows]
 
     def check_flags(self):
