@@ -1,0 +1,125 @@
+"""PaiNN and GCN forwards (layer path on the HIP engine) and MessagePassingBase vs the CPU oracle."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from gcnn_keras_amd import synth
+from oracle import kgcnn_oracle as ko
+
+pytestmark = pytest.mark.gpu
+
+
+def _dev(values, splits):
+    from gcnn_keras_amd.ragged import RaggedTensor
+    return RaggedTensor.from_numpy(values, splits)
+
+
+def _check(got, ref32, ref64, tol=1e-5):
+    scale = float(np.max(np.abs(ref64)))
+    assert got.shape == ref32.shape
+    assert np.max(np.abs(got - ref32)) <= tol * scale, (np.max(np.abs(got - ref32)), scale)
+    err_e, err_o = float(np.max(np.abs(got - ref64))), float(np.max(np.abs(ref32 - ref64)))
+    assert err_e <= max(4 * err_o, 2e-6 * scale), (err_e, err_o, scale)
+
+
+@pytest.mark.parametrize("num_graphs,seed,method,cutoff", [(3, 12, "eps", None), (64, 2345, "eps", None),
+                                                           (4, 7, "zeros", 5.0)])
+def test_painn_forward(num_graphs, seed, method, cutoff, golden_dir):
+    """BASELINE config 3 shape: PAiNN.make_model defaults, Bessel(20, 5.0, 5), equivariant init 'eps'."""
+    from gcnn_keras_amd.literature import PAiNN
+    b = synth.md17_like_batch(num_graphs=num_graphs, seed=seed)
+    p = synth.painn_params(seed=8, random_bias=True)
+    model = PAiNN.make_model(equiv_initialize_kwargs={"dim": 3, "method": method},
+                             conv_args={"units": 128, "cutoff": cutoff, "conv_pool": "sum"})
+    names = [n for n, _ in model.weights]
+    assert len(names) == len(p), (len(names), len(p))
+    # constructor order: embedding, bessel frequencies, then per block conv (dense1, phi, w) and update
+    order = ["embedding", "bessel/frequencies"]
+    for i in range(3):
+        order += ["conv%d/dense1/kernel" % i, "conv%d/dense1/bias" % i, "conv%d/phi/kernel" % i, "conv%d/phi/bias" % i,
+                  "conv%d/w/kernel" % i, "conv%d/w/bias" % i,
+                  "update%d/dense1/kernel" % i, "update%d/dense1/bias" % i, "update%d/lin_u/kernel" % i,
+                  "update%d/lin_v/kernel" % i, "update%d/a/kernel" % i, "update%d/a/bias" % i]
+    order += ["output_mlp/0/kernel", "output_mlp/0/bias", "output_mlp/1/kernel", "output_mlp/1/bias"]
+    model.set_weights([p[k] for k in order])
+    out = model([_dev(b["node_number"], b["node_splits"]), _dev(b["node_coordinates"], b["node_splits"]),
+                 _dev(b["edge_indices"], b["edge_splits"])]).cpu().numpy()
+
+    def oracle(dtype):
+        return ko.painn_forward(ko.to_dtype(p, dtype), ko.R(b["node_number"], b["node_splits"]),
+                                ko.R(b["node_coordinates"].astype(dtype), b["node_splits"]),
+                                ko.R(b["edge_indices"], b["edge_splits"]), depth=3, equiv_method=method, cutoff=cutoff)
+    _check(out, oracle(np.float32), oracle(np.float64))
+    if (num_graphs, seed) == (3, 12):
+        frozen = np.load(os.path.join(golden_dir, "frozen_painn_small.npz"))["out"]
+        assert np.max(np.abs(out - frozen)) <= 1e-5 * np.max(np.abs(frozen))
+
+
+@pytest.mark.parametrize("case", ["small", "cora"])
+def test_gcn_forward(case, golden_dir):
+    """BASELINE config 5 shape: GCN.make_model, units 64, depth 3, node output [64, 32, 7] softmax."""
+    from gcnn_keras_amd.literature import GCN
+    if case == "small":
+        g = synth.cora_like_graph(num_nodes=120, num_features=40, seed=13, drop_pairs=9)
+        feats = 40
+    else:
+        g = synth.cora_like_graph()
+        feats = 1433
+        assert g["edge_splits"][-1] == 10556 + 2708
+    p = synth.gcn_params(seed=9, in_features=feats, random_bias=True)
+    model = GCN.make_model(
+        inputs=[{"shape": (None, feats), "name": "node_attributes", "dtype": "float32", "ragged": True},
+                {"shape": (None, 1), "name": "edge_weights", "dtype": "float32", "ragged": True},
+                {"shape": (None, 2), "name": "edge_indices", "dtype": "int64", "ragged": True}],
+        gcn_args={"units": 64, "use_bias": True, "activation": "relu", "pooling_method": "sum"},
+        depth=3, output_embedding="node", output_to_tensor=False,
+        output_mlp={"use_bias": [True, True, True], "units": [64, 32, 7], "activation": ["relu", "relu", "softmax"]})
+    model.set_weights(list(p.values()))
+    out = model([_dev(g["node_attributes"], g["node_splits"]), _dev(g["edge_weights"], g["edge_splits"]),
+                 _dev(g["edge_indices"], g["edge_splits"])]).values.cpu().numpy()
+
+    def oracle(dtype):
+        return ko.gcn_forward(ko.to_dtype(p, dtype), ko.R(g["node_attributes"].astype(dtype), g["node_splits"]),
+                              ko.R(g["edge_weights"].astype(dtype), g["edge_splits"]),
+                              ko.R(g["edge_indices"], g["edge_splits"])).values
+    _check(out, oracle(np.float32), oracle(np.float64))
+    assert np.allclose(out.sum(-1), 1.0, atol=1e-5)
+    if case == "small":
+        frozen = np.load(os.path.join(golden_dir, "frozen_gcn_small.npz"))["out"]
+        assert np.max(np.abs(out - frozen)) <= 1e-5 * np.max(np.abs(frozen))
+
+
+def test_message_passing_base():
+    """The README API example pattern (reference README.md:118-138): subclass with message / update functions."""
+    from gcnn_keras_amd.layers.message import MessagePassingBase
+    from gcnn_keras_amd.layers.modules import Dense, LazyAdd, LazyConcatenate
+
+    class MyMessageNN(MessagePassingBase):
+        def __init__(self, units, **kwargs):
+            super().__init__(**kwargs)
+            self.dense = Dense(units)
+            self.add = LazyAdd()
+            self.cat = LazyConcatenate(axis=-1)
+
+        def message_function(self, inputs, **kwargs):
+            n_in, n_out, edges = inputs
+            return self.dense(self.cat([n_in, n_out]))
+
+        def update_nodes(self, inputs, **kwargs):
+            nodes, nodes_update = inputs
+            return self.add([nodes, nodes_update])
+
+    t = synth.toy_batch()
+    n = ko.R(np.tile(t["node_attributes"], (1, 1)), t["node_splits"])
+    ei = ko.R(t["edge_indices"], t["edge_splits"])
+    lay = MyMessageNN(3)
+    out = lay([_dev(n.values, n.row_splits), _dev(np.zeros((6, 1), np.float32), t["edge_splits"]),
+               _dev(ei.values, ei.row_splits)])
+    w, bias = lay.dense.get_weights()
+    g = ko.gather_nodes_selection(n, ei, [0, 1])
+    msg = ko.dense(ko.lazy_concatenate(g), w, bias, None)
+    ref = ko.lazy_add([n, ko.pooling_local_edges(n, msg, ei, "sum")])
+    assert np.max(np.abs(out.values.cpu().numpy() - ref.values)) <= 1e-5 * np.max(np.abs(ref.values))
+    assert lay.get_config()["pooling_method"] == "sum"
