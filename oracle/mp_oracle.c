@@ -1,0 +1,214 @@
+/*
+ * mp_oracle.c - plain C / OpenMP restatement of the reference's UNFUSED op sequence for the SchNet forward.
+ *
+ * TEST INFRASTRUCTURE, NOT PRODUCT CODE: used by tests/ (checked against oracle/kgcnn_oracle.py) and by the
+ * cpu_baseline leg of bench.py ("kind": "port").  Parity status: same as kgcnn_oracle.py (pinned by the reference's
+ * four known answers through the NumPy oracle this file is tested against; "parity unpinned" w.r.t. TensorFlow,
+ * which is not installable here).
+ *
+ * Every step materialises its output exactly as the TF graph of the reference does:
+ *   partition_row_indexing (kgcnn/ops/partition.py:140-155) -> tf.gather (kgcnn/layers/gather.py:228) ->
+ *   Dense (kgcnn/layers/modules.py:85) -> multiply (modules.py:301) -> stable argsort + gather by order
+ *   (kgcnn/layers/pooling.py:66-68) -> sorted segment_sum (kgcnn/ops/segment.py:41-42) -> scatter_nd zero pad
+ *   (pooling.py:74-76), wired as kgcnn/layers/conv/schnet_conv.py:73-79,159-165 and kgcnn/literature/Schnet.py:104-148.
+ */
+#include <math.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+#ifdef _OPENMP
+#include <omp.h>
+#endif
+
+enum { ACT_LINEAR = 0, ACT_SSP = 2 };
+
+int mpo_num_threads(void) {
+#ifdef _OPENMP
+  return omp_get_max_threads();
+#else
+  return 1;
+#endif
+}
+
+/* tf.nn.softplus thresholds (see kgcnn_oracle.softplus) minus log(2): kgcnn/ops/activ.py:15 */
+static inline float ssp(float x) {
+  const float thr = -13.942385f;
+  float sp;
+  if (x > -thr) sp = x;
+  else if (x < thr) sp = expf(x);
+  else sp = log1pf(expf(x));
+  return sp - 0.6931471805599453f;
+}
+
+/* kgcnn/ops/partition.py:140-155: out[e,k] = idx[e,k] + node_splits[graph_of(e)] */
+static void shift_index(const int64_t* idx, int64_t M, const int64_t* node_splits, const int64_t* edge_splits,
+                        int64_t G, int64_t* out) {
+#pragma omp parallel for schedule(static)
+  for (int64_t g = 0; g < G; ++g)
+    for (int64_t e = edge_splits[g]; e < edge_splits[g + 1]; ++e) {
+      out[2 * e] = idx[2 * e] + node_splits[g];
+      out[2 * e + 1] = idx[2 * e + 1] + node_splits[g];
+    }
+  (void)M;
+}
+
+/* tf.gather(x, idx[:, col], axis=0) */
+static void gather_rows(const float* x, int64_t F, const int64_t* shifted, int col, int64_t M, float* out) {
+#pragma omp parallel for schedule(static)
+  for (int64_t e = 0; e < M; ++e) memcpy(out + e * F, x + shifted[2 * e + col] * F, sizeof(float) * (size_t)F);
+}
+
+/* Keras Dense: out = act(x @ W + b), W (K,U) row-major */
+static void dense(const float* x, int64_t R, int64_t K, const float* W, const float* b, int64_t U, int act,
+                  float* out) {
+#pragma omp parallel for schedule(static)
+  for (int64_t r = 0; r < R; ++r) {
+    float* o = out + r * U;
+    for (int64_t u = 0; u < U; ++u) o[u] = 0.0f;
+    const float* xr = x + r * K;
+    for (int64_t k = 0; k < K; ++k) {
+      const float xv = xr[k];
+      const float* w = W + k * U;
+      for (int64_t u = 0; u < U; ++u) o[u] += xv * w[u];
+    }
+    for (int64_t u = 0; u < U; ++u) {
+      float v = o[u] + (b ? b[u] : 0.0f);
+      o[u] = act == ACT_SSP ? ssp(v) : v;
+    }
+  }
+}
+
+/* PoolingLocalEdges(sum), kgcnn/layers/pooling.py:63-78: stable argsort by receiver, gather by order, sorted
+ * segment_sum (sequential per segment), zero pad to N rows. */
+static void pooling_local_edges_sum(const float* edges, int64_t M, int64_t F, const int64_t* shifted, int64_t N,
+                                    float* out, int64_t* order, int64_t* count, float* sorted) {
+  /* stable counting sort == tf.argsort(stable=True) */
+  memset(count, 0, sizeof(int64_t) * (size_t)(N + 1));
+  for (int64_t e = 0; e < M; ++e) count[shifted[2 * e] + 1]++;
+  for (int64_t n = 0; n < N; ++n) count[n + 1] += count[n];
+  {
+    int64_t* cursor = (int64_t*)malloc(sizeof(int64_t) * (size_t)(N + 1));
+    memcpy(cursor, count, sizeof(int64_t) * (size_t)(N + 1));
+    for (int64_t e = 0; e < M; ++e) order[cursor[shifted[2 * e]]++] = e;
+    free(cursor);
+  }
+  /* dens = tf.gather(dens, node_order): the full (M,F) copy the reference makes */
+#pragma omp parallel for schedule(static)
+  for (int64_t k = 0; k < M; ++k) memcpy(sorted + k * F, edges + order[k] * F, sizeof(float) * (size_t)F);
+  /* segment_sum + scatter_nd pad */
+#pragma omp parallel for schedule(static)
+  for (int64_t n = 0; n < N; ++n) {
+    float* o = out + n * F;
+    for (int64_t f = 0; f < F; ++f) o[f] = 0.0f;
+    for (int64_t k = count[n]; k < count[n + 1]; ++k) {
+      const float* s = sorted + k * F;
+      for (int64_t f = 0; f < F; ++f) o[f] += s[f];
+    }
+  }
+}
+
+/*
+ * SchNet forward (graph output).  Weight pointers in constructor order (gcnn_keras_amd.synth.schnet_params):
+ * emb (vocab,64); W0 (64,F) b0; per block: cW1 (B,F) cb1 cW2 (F,F) cb2 | d1 (F,F) | d2 (F,F) b2 | d3 (F,F) b3;
+ * last_mlp (F,F)+b,(F,64)+b ; output_mlp (64,64)+b,(64,1)+b.  Returns 0, or -1 on allocation failure.
+ */
+int mpo_schnet_forward(const float* z, const float* xyz, const int64_t* idx, const int64_t* node_splits,
+                       const int64_t* edge_splits, int64_t G, int depth, int bins, float g_distance, float g_sigma,
+                       float g_offset, const float* const* weights, int vocab, float* out /* (G,1) */) {
+  const int64_t N = node_splits[G], M = edge_splits[G], F = 128, E = 64;
+  const float gamma = (float)(1.0 / (double)g_sigma / (double)g_sigma / 2.0);
+  int wi = 0;
+  const float* emb = weights[wi++];
+  const float* W0 = weights[wi++];
+  const float* b0 = weights[wi++];
+
+  int64_t* shifted = (int64_t*)malloc(sizeof(int64_t) * 2 * (size_t)(M > 0 ? M : 1));
+  int64_t* order = (int64_t*)malloc(sizeof(int64_t) * (size_t)(M > 0 ? M : 1));
+  int64_t* count = (int64_t*)malloc(sizeof(int64_t) * (size_t)(N + 2));
+  float* n0 = (float*)malloc(sizeof(float) * (size_t)(N * E + 1));
+  float* n = (float*)malloc(sizeof(float) * (size_t)(N * F + 1));
+  float* x = (float*)malloc(sizeof(float) * (size_t)(N * F + 1));
+  float* t1 = (float*)malloc(sizeof(float) * (size_t)(N * F + 1));
+  float* t2 = (float*)malloc(sizeof(float) * (size_t)(N * F + 1));
+  float* agg = (float*)malloc(sizeof(float) * (size_t)(N * F + 1));
+  float* pos = (float*)malloc(sizeof(float) * 6 * (size_t)(M > 0 ? M : 1));
+  float* rbf = (float*)malloc(sizeof(float) * (size_t)(M * bins + 1));
+  float* h1 = (float*)malloc(sizeof(float) * (size_t)(M * F + 1));
+  float* h2 = (float*)malloc(sizeof(float) * (size_t)(M * F + 1));
+  float* xj = (float*)malloc(sizeof(float) * (size_t)(M * F + 1));
+  float* srt = (float*)malloc(sizeof(float) * (size_t)(M * F + 1));
+  float* pooled = (float*)malloc(sizeof(float) * (size_t)(G * 64 + 1));
+  float* o1 = (float*)malloc(sizeof(float) * (size_t)(G * 64 + 1));
+  if (!shifted || !order || !count || !n0 || !n || !x || !t1 || !t2 || !agg || !pos || !rbf || !h1 || !h2 || !xj ||
+      !srt || !pooled || !o1)
+    return -1;
+
+  /* OptionalInputEmbedding: float numbers cast to int32 (Keras Embedding) */
+#pragma omp parallel for schedule(static)
+  for (int64_t i = 0; i < N; ++i) {
+    int zi = (int)z[i];
+    if (zi < 0) zi = 0;
+    if (zi >= vocab) zi = vocab - 1;
+    memcpy(n0 + i * E, emb + (int64_t)zi * E, sizeof(float) * (size_t)E);
+  }
+  /* NodePosition (two gathers), NodeDistanceEuclidean, GaussBasisLayer */
+  shift_index(idx, M, node_splits, edge_splits, G, shifted);
+#pragma omp parallel for schedule(static)
+  for (int64_t e = 0; e < M; ++e) {
+    memcpy(pos + 6 * e, xyz + shifted[2 * e] * 3, sizeof(float) * 3);
+    memcpy(pos + 6 * e + 3, xyz + shifted[2 * e + 1] * 3, sizeof(float) * 3);
+  }
+#pragma omp parallel for schedule(static)
+  for (int64_t e = 0; e < M; ++e) {
+    const float dx = pos[6 * e] - pos[6 * e + 3], dy = pos[6 * e + 1] - pos[6 * e + 4],
+                dz = pos[6 * e + 2] - pos[6 * e + 5];
+    const float d = sqrtf(fmaxf(dx * dx + dy * dy + dz * dz, 0.0f));
+    for (int k = 0; k < bins; ++k) {
+      const float mu = (float)k / (float)bins * g_distance;
+      const float v = (d - g_offset) - mu;
+      rbf[e * bins + k] = expf((v * v) * (gamma * -1.0f));
+    }
+  }
+  dense(n0, N, E, W0, b0, F, ACT_LINEAR, n);
+  for (int blk = 0; blk < depth; ++blk) {
+    const float* cW1 = weights[wi++]; const float* cb1 = weights[wi++];
+    const float* cW2 = weights[wi++]; const float* cb2 = weights[wi++];
+    const float* d1 = weights[wi++];
+    const float* d2 = weights[wi++]; const float* db2 = weights[wi++];
+    const float* d3 = weights[wi++]; const float* db3 = weights[wi++];
+    dense(n, N, F, d1, NULL, F, ACT_LINEAR, x);                 /* schnet_conv.py:160 */
+    dense(rbf, M, bins, cW1, cb1, F, ACT_SSP, h1);              /* :74 */
+    dense(h1, M, F, cW2, cb2, F, ACT_LINEAR, h2);               /* :75 */
+    shift_index(idx, M, node_splits, edge_splits, G, shifted);  /* recomputed by every gather / pooling call */
+    gather_rows(x, F, shifted, 1, M, xj);                       /* :76 */
+#pragma omp parallel for schedule(static)
+    for (int64_t i = 0; i < M * F; ++i) xj[i] = xj[i] * h2[i];  /* :77 */
+    shift_index(idx, M, node_splits, edge_splits, G, shifted);
+    pooling_local_edges_sum(xj, M, F, shifted, N, agg, order, count, srt); /* :78 */
+    dense(agg, N, F, d2, db2, F, ACT_SSP, t1);                  /* :162 */
+    dense(t1, N, F, d3, db3, F, ACT_LINEAR, t2);                /* :163 */
+#pragma omp parallel for schedule(static)
+    for (int64_t i = 0; i < N * F; ++i) n[i] = n[i] + t2[i];    /* :164 */
+  }
+  {
+    const float* L0 = weights[wi++]; const float* lb0 = weights[wi++];
+    const float* L1 = weights[wi++]; const float* lb1 = weights[wi++];
+    const float* O0 = weights[wi++]; const float* ob0 = weights[wi++];
+    const float* O1 = weights[wi++]; const float* ob1 = weights[wi++];
+    dense(n, N, F, L0, lb0, F, ACT_SSP, t1);
+    dense(t1, N, F, L1, lb1, 64, ACT_SSP, t2);
+    /* PoolingNodes(sum): sequential per graph */
+#pragma omp parallel for schedule(static)
+    for (int64_t g = 0; g < G; ++g) {
+      float* p = pooled + g * 64;
+      for (int f = 0; f < 64; ++f) p[f] = 0.0f;
+      for (int64_t i = node_splits[g]; i < node_splits[g + 1]; ++i)
+        for (int f = 0; f < 64; ++f) p[f] += t2[i * 64 + f];
+    }
+    dense(pooled, G, 64, O0, ob0, 64, ACT_SSP, o1);
+    dense(o1, G, 64, O1, ob1, 1, ACT_LINEAR, out);
+  }
+  free(shifted); free(order); free(count); free(n0); free(n); free(x); free(t1); free(t2); free(agg); free(pos);
+  free(rbf); free(h1); free(h2); free(xj); free(srt); free(pooled); free(o1);
+  return 0;
+}

@@ -107,3 +107,21 @@ def test_frozen_model_outputs(golden_dir):
                          ko.R(g["edge_indices"], g["edge_splits"]))
     np.testing.assert_allclose(out.values, np.load(os.path.join(golden_dir, "frozen_gcn_small.npz"))["out"],
                                rtol=1e-5, atol=1e-6)
+
+
+def test_c_oracle_matches_numpy_oracle():
+    """oracle/mp_oracle.c (the cpu_baseline port) against the pinned NumPy oracle on the seeded config-2-shaped batch."""
+    from oracle import c_oracle
+    if not c_oracle.available():
+        pytest.skip("oracle/libmp_oracle.so not built (run __graft_entry__.build())")
+    for graphs, seed in [(6, 11), (32, 1234)]:
+        b = synth.qm9_like_batch(num_graphs=graphs, seed=seed)
+        p = synth.schnet_params(seed=7, random_bias=True)
+        ref = ko.schnet_forward(p, ko.R(b["node_number"], b["node_splits"]),
+                                ko.R(b["node_coordinates"], b["node_splits"]),
+                                ko.R(b["edge_indices"], b["edge_splits"]), depth=3)
+        got = c_oracle.schnet_forward(p, b["node_number"], b["node_coordinates"], b["edge_indices"], b["node_splits"],
+                                      b["edge_splits"], depth=3)
+        assert got.shape == ref.shape
+        assert np.max(np.abs(got - ref)) <= 1e-5 * np.max(np.abs(ref))
+    assert c_oracle.num_threads() >= 1
