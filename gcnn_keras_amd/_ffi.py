@@ -72,6 +72,12 @@ _SIGNATURES = {
     "mp_schnet_node_update_f32": [P, c_int64, P, P, P, P, P, P, P, P],
     "mp_schnet_node_last_f32": [P, c_int64, P, P, P, P, P, P, P, P, P, P, P],
     "mp_schnet_readout_f32": [P, P, c_int64, P, P, P, P, P, P],
+    "mp_activation_grad_f32": [c_int, c_float, P, P, c_int64, P, P],
+    "mp_sum_axis_f32": [P, c_int64, c_int64, c_int64, c_int, P, P],
+    "mp_euclidean_norm_grad_f32": [P, P, c_int64, c_int64, c_int64, c_int, P, P],
+    "mp_bessel_basis_grad_f32": [P, c_int64, P, c_int, c_float, c_int, P, P, P],
+    "mp_gauss_basis_grad_f32": [P, c_int64, c_int, c_float, c_float, c_float, P, P, P],
+    "mp_cos_cutoff_grad_f32": [P, c_int64, c_float, P, P, P],
 }
 _RESTYPES = {"mp_last_error": c_char_p}
 

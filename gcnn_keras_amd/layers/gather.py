@@ -13,6 +13,13 @@ from .base import GraphBaseLayer
 
 def gather_rows(values, plan, colsel):
     """rows of ``values`` (N, ...) at plan columns ``colsel`` -> (M, len(colsel), ...) contiguous."""
+    from ..autograd import GatherRows, needs_grad
+    if needs_grad(values):
+        return GatherRows.apply(values, plan, tuple(colsel))
+    return _gather_rows_raw(values, plan, colsel)
+
+
+def _gather_rows_raw(values, plan, colsel):
     _ffi.require_device(values)
     vals = values.contiguous()
     elems = 1

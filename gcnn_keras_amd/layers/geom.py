@@ -69,6 +69,9 @@ class EuclideanNorm(GraphBaseLayer):
         out_shape = shape[:ax] + ([1] if keepdims else []) + shape[ax + 1:]
         out = torch.empty(out_shape, dtype=torch.float32, device=x.device)
         flags = (1 if invert_norm else 0) | (2 if add_eps else 0) | (4 if no_nan else 0) | (8 if square_norm else 0)
+        from ..autograd import EuclideanNorm as NormFn, needs_grad
+        if needs_grad(inputs):
+            return NormFn.apply(inputs, r, d, c, flags, tuple(out_shape))
         _ffi.call("mp_euclidean_norm_f32", _ffi.ptr(x), r, d, c, flags, _ffi.ptr(out), _ffi.stream())
         return out
 
@@ -100,6 +103,9 @@ class ScalarProduct(GraphBaseLayer):
 
     @staticmethod
     def _scalar_product(inputs: list, axis: int, **kwargs):
+        from ..autograd import ScalarProduct as ProdFn, needs_grad
+        if needs_grad(inputs[0], inputs[1]):
+            return ProdFn.apply(inputs[0], inputs[1], axis)
         a, b = inputs[0].contiguous(), inputs[1].contiguous()
         _ffi.require_device(a, b)
         r, d, c = _rdc(a, axis)
@@ -175,6 +181,9 @@ class GaussBasisLayer(GraphBaseLayer):
         d = inputs.contiguous()
         if int(d.shape[-1]) != 1:
             raise ValueError("GaussBasisLayer expects distances of shape (batch, [K], 1)")
+        from ..autograd import GaussBasis as GaussFn, needs_grad
+        if needs_grad(inputs):
+            return GaussFn.apply(inputs, self.bins, self.distance, self.sigma, self.offset)
         m = d.numel()
         out = torch.empty(tuple(d.shape[:-1]) + (self.bins,), dtype=torch.float32, device=d.device)
         _ffi.call("mp_gauss_basis_f32", _ffi.ptr(d), m, self.bins, self.distance, self.sigma, self.offset,
@@ -212,6 +221,10 @@ class BesselBasisLayer(GraphBaseLayer):
         d = inputs.contiguous()
         if int(d.shape[-1]) != 1:
             raise ValueError("BesselBasisLayer expects distances of shape (batch, [K], 1)")
+        from ..autograd import BesselBasis as BesselFn, needs_grad
+        if needs_grad(inputs):
+            return BesselFn.apply(inputs, self.frequencies, self.num_radial, float(self.cutoff),
+                                  int(self.envelope_exponent))
         out = torch.empty(tuple(d.shape[:-1]) + (self.num_radial,), dtype=torch.float32, device=d.device)
         _ffi.call("mp_bessel_basis_f32", _ffi.ptr(d), d.numel(), _ffi.ptr(self.frequencies), self.num_radial,
                   float(self.cutoff), int(self.envelope_exponent), _ffi.ptr(out), _ffi.stream())
@@ -236,6 +249,9 @@ class CosCutOffEnvelope(GraphBaseLayer):
 
     def _compute_cutoff_envelope(self, inputs):
         _ffi.require_device(inputs)
+        from ..autograd import CosCutoff as CosFn, needs_grad
+        if needs_grad(inputs):
+            return CosFn.apply(inputs, float(self.cutoff))
         d = inputs.contiguous()
         out = torch.empty_like(d)
         _ffi.call("mp_cos_cutoff_f32", _ffi.ptr(d), d.numel(), float(self.cutoff), _ffi.ptr(out), _ffi.stream())

@@ -16,26 +16,32 @@ def _activation_name(activation):
     return activation
 
 
-def dense_values(x, kernel, bias, activation="linear", alpha=0.05):
-    """``act(x @ kernel + bias)`` on the last axis of a values tensor via ``mp_dense_f32`` (FP32 MFMA)."""
-    _ffi.require_device(x, kernel)
-    if x.dtype != torch.float32:
-        raise TypeError("Dense expects float32 values, got %s" % x.dtype)
+def _dense_raw(x, kernel, bias, act_code, alpha):
     k = int(x.shape[-1])
-    if k != int(kernel.shape[0]):
-        raise ValueError("Dense kernel expects last dimension %d, got %d" % (int(kernel.shape[0]), k))
     u = int(kernel.shape[1])
     xc = x.contiguous()
     rows = xc.numel() // max(k, 1)
     out = torch.empty(tuple(x.shape[:-1]) + (u,), dtype=torch.float32, device=x.device)
-    name = _activation_name(activation)
-    if name == "softmax":
-        _ffi.call("mp_dense_f32", _ffi.ptr(xc), rows, k, _ffi.ptr(kernel), _ffi.ptr(bias), u, 0, 0.0, _ffi.ptr(out),
-                  _ffi.stream())
-        return softmax(out)
-    _ffi.call("mp_dense_f32", _ffi.ptr(xc), rows, k, _ffi.ptr(kernel), _ffi.ptr(bias), u, _ffi.activation_code(name),
-              float(alpha), _ffi.ptr(out), _ffi.stream())
+    _ffi.call("mp_dense_f32", _ffi.ptr(xc), rows, k, _ffi.ptr(kernel), _ffi.ptr(bias), u, act_code, float(alpha),
+              _ffi.ptr(out), _ffi.stream())
     return out
+
+
+def dense_values(x, kernel, bias, activation="linear", alpha=0.05):
+    """``act(x @ kernel + bias)`` on the last axis of a values tensor via ``mp_dense_f32`` (FP32 MFMA)."""
+    from ..autograd import Dense as DenseFn, needs_grad
+    _ffi.require_device(x, kernel)
+    if x.dtype != torch.float32:
+        raise TypeError("Dense expects float32 values, got %s" % x.dtype)
+    if int(x.shape[-1]) != int(kernel.shape[0]):
+        raise ValueError("Dense kernel expects last dimension %d, got %d" % (int(kernel.shape[0]), int(x.shape[-1])))
+    name = _activation_name(activation)
+    code = 0 if name == "softmax" else _ffi.activation_code(name)
+    if needs_grad(x):
+        out = DenseFn.apply(x, kernel, bias, code, float(alpha))
+    else:
+        out = _dense_raw(x, kernel, bias, code, alpha)
+    return softmax(out) if name == "softmax" else out
 
 
 class DenseEmbedding(GraphBaseLayer):
@@ -133,6 +139,13 @@ Dropout = DropoutEmbedding
 
 def binary_values(op, a, b):
     """Broadcasting elementwise op on two values tensors of equal rank (<= 3 non-unit groups)."""
+    from ..autograd import Binary, needs_grad
+    if needs_grad(a, b):
+        return Binary.apply(a, b, op)
+    return _binary_raw(op, a, b)
+
+
+def _binary_raw(op, a, b):
     _ffi.require_device(a, b)
     if a.dim() != b.dim():
         raise ValueError("operands must have equal rank: %s vs %s" % (tuple(a.shape), tuple(b.shape)))
@@ -222,6 +235,13 @@ class LazyMultiply(GraphBaseLayer):
 
 def concat_last(values):
     """``tf.concat(values, axis=-1)`` by strided column-block copies."""
+    from ..autograd import ConcatLast, needs_grad
+    if needs_grad(*values):
+        return ConcatLast.apply(*values)
+    return _concat_last_raw(values)
+
+
+def _concat_last_raw(values):
     _ffi.require_device(*values)
     lead = tuple(values[0].shape[:-1])
     widths = [int(v.shape[-1]) for v in values]
@@ -241,6 +261,13 @@ def concat_last(values):
 
 def split_last(value, num):
     """``tf.split(value, num, axis=-1)`` into contiguous tensors."""
+    from ..autograd import SplitLast, needs_grad
+    if needs_grad(value):
+        return list(SplitLast.apply(value, num))
+    return _split_last_raw(value, num)
+
+
+def _split_last_raw(value, num):
     _ffi.require_device(value)
     vc = value.contiguous()
     total = int(vc.shape[-1])

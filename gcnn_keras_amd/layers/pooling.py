@@ -22,7 +22,8 @@ def _pool_local(layer, nodes, edges, idx, op, weights=None, normalize=False):
         # reference: rows = max(receiver) + 1 (kgcnn/layers/pooling.py:71-76 without the scatter_nd pad)
         n_out = int(seg[-1].item()) + 1 if plan.M > 0 else 0
     w = None if weights is None else weights.values
-    out = segment_reduce_csr(op, edges.values, ptr, perm, n_out, weight=w, normalize_by_weight=normalize)
+    out = segment_reduce_csr(op, edges.values, ptr, perm, n_out, weight=w, normalize_by_weight=normalize,
+                             seg_ids=plan.col(layer.pooling_index))
     return nodes.with_values(out)
 
 
@@ -84,6 +85,16 @@ def _pool_graph(x, op, weights=None):
     _ffi.require_device(x.values, x.row_splits)
     vals = x.values.contiguous()
     g = x.nrows()
+    from ..autograd import PoolGraph, needs_grad
+    if needs_grad(vals):
+        if weights is not None:
+            raise NotImplementedError("gradient of weighted graph pooling is outside the force path")
+        out = PoolGraph.apply(vals, op, x.row_splits, g)
+        splits = x.row_splits_host()
+        rows = g
+        while rows > 0 and splits[rows] == splits[rows - 1]:
+            rows -= 1
+        return out[:rows] if rows != g else out
     elems = 1
     for d in vals.shape[1:]:
         elems *= int(d)

@@ -9,6 +9,9 @@ def apply_activation(name, x, alpha=0.05):
     if code == 0:
         return x
     _ffi.require_device(x)
+    from ..autograd import Activation, needs_grad
+    if needs_grad(x):
+        return Activation.apply(x, code, float(alpha))
     xc = x.contiguous()
     out = torch.empty_like(xc)
     _ffi.call("mp_activation_f32", code, float(alpha), _ffi.ptr(xc), xc.numel(), _ffi.ptr(out), _ffi.stream())

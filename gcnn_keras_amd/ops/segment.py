@@ -34,8 +34,18 @@ def csr_from_sorted_ids(segment_ids, num_segments):
     return ptr
 
 
-def segment_reduce_csr(op, data, ptr, perm, n_out, weight=None, normalize_by_weight=False):
-    """out[n] = op over rows [ptr[n], ptr[n+1]) of ``data`` (through ``perm`` if given); rows without members are 0."""
+def segment_reduce_csr(op, data, ptr, perm, n_out, weight=None, normalize_by_weight=False, seg_ids=None):
+    """out[n] = op over rows [ptr[n], ptr[n+1]) of ``data`` (through ``perm`` if given); rows without members are 0.
+    ``seg_ids`` (segment id per row, original order) is only needed when a gradient w.r.t. ``data`` is requested."""
+    from ..autograd import SegmentSum, needs_grad
+    if needs_grad(data):
+        if seg_ids is None or normalize_by_weight:
+            raise NotImplementedError("gradient needs the segment ids and no weight normalisation")
+        return SegmentSum.apply(data, op, ptr, perm, n_out, weight, seg_ids)
+    return _segment_reduce_raw(op, data, ptr, perm, n_out, weight, normalize_by_weight)
+
+
+def _segment_reduce_raw(op, data, ptr, perm, n_out, weight=None, normalize_by_weight=False):
     _ffi.require_device(data, ptr)
     flat, m, elems = _flat2d(data)
     out = torch.empty((n_out,) + tuple(data.shape[1:]), dtype=torch.float32, device=data.device)

@@ -225,6 +225,22 @@ int mp_schnet_node_last_f32(float* agg, int64_t N, const float* W2, const float*
 int mp_schnet_readout_f32(const float* h, const int64_t* node_splits, int64_t G, const float* Wo0, const float* bo0,
                           const float* Wo1, const float* bo1, float* out, mpStream_t stream);
 
+/* ---------------------------------------------------------------- backward helpers (forces) -------------- */
+/* EnergyForceModel, kgcnn/model/force.py:159-186: F = -dE/dx needs one reverse pass.  Gather-backward is
+ * mp_segment_reduce_csr_f32 over the CSR of the gathered column, segment-sum-backward is mp_gather_rows_f32 by the
+ * receiver ids, Dense-backward is mp_dense_f32 with the transposed kernel; these are the remaining derivatives. */
+int mp_activation_grad_f32(int act, float act_alpha, const float* pre, const float* gy, int64_t n, float* out,
+                           mpStream_t stream);                       /* out = gy * act'(pre) */
+int mp_sum_axis_f32(const float* x, int64_t R, int64_t D1, int64_t D2, int axis /* 1 or 2 */, float* out,
+                    mpStream_t stream);                              /* un-broadcast of mp_binary_f32 operands */
+int mp_euclidean_norm_grad_f32(const float* x, const float* gy, int64_t R, int64_t D, int64_t C, int flags, float* gx,
+                               mpStream_t stream);                   /* geom.py:181-193 */
+int mp_bessel_basis_grad_f32(const float* d, int64_t M, const float* frequencies, int num_radial, float cutoff,
+                             int envelope_exponent, const float* gy, float* gd, mpStream_t stream); /* geom.py:772-785 */
+int mp_gauss_basis_grad_f32(const float* d, int64_t M, int bins, float distance, float sigma, float offset,
+                            const float* gy, float* gd, mpStream_t stream);                         /* geom.py:567-571 */
+int mp_cos_cutoff_grad_f32(const float* d, int64_t n, float cutoff, const float* gy, float* gd, mpStream_t stream);
+
 #ifdef __cplusplus
 }
 #endif
