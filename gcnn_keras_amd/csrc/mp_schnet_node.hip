@@ -23,6 +23,14 @@ constexpr int F = 128;
 constexpr int X_LD = 130;  // padded row stride of the LDS activation tiles: (2*node + k) mod 32 is conflict-free
 
 __device__ __forceinline__ float ssp_exact(float x) { return mp_softplus(x) - 0.6931471805599453f; }
+// v_exp_f32 / v_log_f32 form of the shifted softplus (same as csrc/mp_cfconv.hip; |delta| < 2e-7 vs ssp_exact)
+__device__ __forceinline__ float ssp_fast(float x) {
+  const float t = __builtin_amdgcn_exp2f(fabsf(x) * -1.4426950408889634f);
+  const float l = __builtin_amdgcn_logf(1.0f + t);
+  return fmaf(l - 1.0f, 0.6931471805599453f, fmaxf(x, 0.0f));
+}
+template <bool FAST>
+__device__ __forceinline__ float ssp(float x) { return FAST ? ssp_fast(x) : ssp_exact(x); }
 
 // Slice of W (K x U, row-major) for output columns col0 + 16*cb + (lane&15), k = 4*s + (lane>>4).
 template <int K, int NCB>
@@ -95,8 +103,8 @@ enum NodeMode { NODE_IN = 0, NODE_MID = 1, NODE_LAST = 2 };
     }                                                                 \
   }
 
-template <int MODE, int E, int RB>
-__global__ __launch_bounds__(256) void schnet_node_kernel(NodeArgs a) {
+template <int MODE, int E, int RB, bool FAST>
+__global__ __launch_bounds__(256, (RB == 4 && MODE != NODE_LAST) ? 2 : 1) void schnet_node_kernel(NodeArgs a) {
   constexpr int TN = 16 * RB;  // nodes per tile
   __shared__ float Xa[TN * X_LD];
   __shared__ float Xb[TN * X_LD];
@@ -170,8 +178,9 @@ __global__ __launch_bounds__(256) void schnet_node_kernel(NodeArgs a) {
 
     floatx4 acc[RB][2];
     // residual rows of n, requested now so that the round trip hides under GEMM 1 and 2
-    float n_res[RB][2][4];
-    if constexpr (MODE != NODE_IN) {
+    constexpr bool PREFETCH_N = RB == 1;  // the 64-node build spends its registers on two workgroups per CU instead
+    float n_res[PREFETCH_N ? RB : 1][2][4];
+    if constexpr (MODE != NODE_IN && PREFETCH_N) {
       MP_FOR_OUT(cb, r, row, col, {
         n_res[rb][cb][r] = (node0 + row < a.N) ? a.n[(node0 + row) * F + col] : 0.0f;
       })
@@ -184,7 +193,7 @@ __global__ __launch_bounds__(256) void schnet_node_kernel(NodeArgs a) {
     gemm_tile<(MODE == NODE_IN ? E : F), 2, RB>(Xa, lane, w_first, acc);
     MP_FOR_OUT(cb, r, row, col, {
       float v = acc[rb][cb][r] + bias_first[cb];
-      if constexpr (MODE != NODE_IN) v = ssp_exact(v);
+      if constexpr (MODE != NODE_IN) v = ssp<FAST>(v);
       Xb[row * X_LD + col] = v;
       if constexpr (MODE == NODE_IN) {
         if (node0 + row < a.N) a.n[(node0 + row) * F + col] = v;
@@ -203,7 +212,9 @@ __global__ __launch_bounds__(256) void schnet_node_kernel(NodeArgs a) {
       MP_FOR_OUT(cb, r, row, col, {
         const bool ok = node0 + row < a.N;
         const float y = acc[rb][cb][r] + bias_second[cb];
-        const float nv = n_res[rb][cb][r];
+        float nv;
+        if constexpr (PREFETCH_N) nv = n_res[rb][cb][r];
+        else nv = ok ? a.n[(node0 + row) * F + col] : 0.0f;
         const float nn = nv + y;  // LazyAdd([node, x])
         if (ok && MODE == NODE_MID) a.n[(node0 + row) * F + col] = nn;
         Xa[row * X_LD + col] = nn;
@@ -218,7 +229,7 @@ __global__ __launch_bounds__(256) void schnet_node_kernel(NodeArgs a) {
           if (node0 + row < a.N) a.x[(node0 + row) * F + col] = acc[rb][cb][r];
         })
       } else {
-        MP_FOR_OUT(cb, r, row, col, { Xb[row * X_LD + col] = ssp_exact(acc[rb][cb][r] + bias_third[cb]); })
+        MP_FOR_OUT(cb, r, row, col, { Xb[row * X_LD + col] = ssp<FAST>(acc[rb][cb][r] + bias_third[cb]); })
         __syncthreads();
         // ---- GEMM 4 (LAST): h = ssp(u @ Wl1 + bl1), 64 output columns = 16 per wave ------------------------------
         floatx4 acc4[RB][1];
@@ -231,7 +242,7 @@ __global__ __launch_bounds__(256) void schnet_node_kernel(NodeArgs a) {
           for (int r = 0; r < 4; ++r) {
             const int row = 16 * rb + 4 * (lane >> 4) + r;
             const int col = wave * 16 + (lane & 15);
-            if (node0 + row < a.N) a.h[(node0 + row) * 64 + col] = ssp_exact(acc4[rb][0][r] + bias_fourth);
+            if (node0 + row < a.N) a.h[(node0 + row) * 64 + col] = ssp<FAST>(acc4[rb][0][r] + bias_fourth);
           }
       }
     }
@@ -284,19 +295,24 @@ __global__ __launch_bounds__(256) void schnet_readout_kernel(const float* __rest
 // Small batches (every 16-node tile gets a workgroup of its own on the 256 CUs) are latency bound: 16-node tiles.
 // Large batches are throughput bound: 64-node tiles (each weight register feeds 4 MFMAs, 4x fewer barriers per node)
 // and two workgroups per CU so that one tile's barriers / epilogue hide under the other's MFMAs.
-template <int MODE, int E>
-int launch_node(NodeArgs a, hipStream_t s, const char* what) {
+template <int MODE, int E, bool FAST>
+int launch_node_impl(NodeArgs a, hipStream_t s, const char* what) {
   const int64_t tiles16 = (a.N + 15) / 16;
   if (tiles16 <= 1024) {
     a.ntiles = static_cast<int>(tiles16);
     const int grid = a.ntiles < 512 ? a.ntiles : 512;
-    schnet_node_kernel<MODE, E, 1><<<grid, 256, 0, s>>>(a);
+    schnet_node_kernel<MODE, E, 1, FAST><<<grid, 256, 0, s>>>(a);
   } else {
     a.ntiles = static_cast<int>((a.N + 63) / 64);
     const int grid = a.ntiles < 512 ? a.ntiles : 512;
-    schnet_node_kernel<MODE, E, 4><<<grid, 256, 0, s>>>(a);
+    schnet_node_kernel<MODE, E, 4, FAST><<<grid, 256, 0, s>>>(a);
   }
   return mp::check_launch(what);
+}
+
+template <int MODE, int E>
+int launch_node(const NodeArgs& a, int flags, hipStream_t s, const char* what) {
+  return (flags & 1) ? launch_node_impl<MODE, E, true>(a, s, what) : launch_node_impl<MODE, E, false>(a, s, what);
 }
 
 }  // namespace
@@ -304,7 +320,7 @@ int launch_node(NodeArgs a, hipStream_t s, const char* what) {
 extern "C" {
 
 int mp_schnet_node_in_f32(const float* numbers, int64_t N, const float* emb, int vocab, int emb_dim, const float* W0,
-                          const float* b0, const float* Wx, float* n_out, float* x_out, mpStream_t stream) {
+                          const float* b0, const float* Wx, float* n_out, float* x_out, int flags, mpStream_t stream) {
   MP_REQUIRE(N >= 0 && vocab >= 1, "mp_schnet_node_in_f32: bad sizes");
   MP_REQUIRE(emb_dim == 64, "mp_schnet_node_in_f32: built for embedding width 64 (got %d)", emb_dim);
   if (N == 0) return MP_OK;
@@ -312,23 +328,24 @@ int mp_schnet_node_in_f32(const float* numbers, int64_t N, const float* emb, int
   NodeArgs a{};
   a.N = N;
   a.numbers = numbers; a.emb = emb; a.vocab = vocab; a.W0 = W0; a.b0 = b0; a.Wx = Wx; a.n = n_out; a.x = x_out;
-  return launch_node<NODE_IN, 64>(a, mp::as_stream(stream), "mp_schnet_node_in_f32");
+  return launch_node<NODE_IN, 64>(a, flags, mp::as_stream(stream), "mp_schnet_node_in_f32");
 }
 
 int mp_schnet_node_update_f32(float* agg, int64_t N, const float* W2, const float* b2, const float* W3,
-                              const float* b3, float* n_inout, const float* Wx_next, float* x_out, mpStream_t stream) {
+                              const float* b3, float* n_inout, const float* Wx_next, float* x_out, int flags,
+                              mpStream_t stream) {
   MP_REQUIRE(N >= 0, "mp_schnet_node_update_f32: bad sizes");
   if (N == 0) return MP_OK;
   MP_REQUIRE(agg && W2 && W3 && n_inout && Wx_next && x_out, "mp_schnet_node_update_f32: null pointer");
   NodeArgs a{};
   a.N = N;
   a.agg = agg; a.W2 = W2; a.b2 = b2; a.W3 = W3; a.b3 = b3; a.n = n_inout; a.Wx = Wx_next; a.x = x_out;
-  return launch_node<NODE_MID, 64>(a, mp::as_stream(stream), "mp_schnet_node_update_f32");
+  return launch_node<NODE_MID, 64>(a, flags, mp::as_stream(stream), "mp_schnet_node_update_f32");
 }
 
 int mp_schnet_node_last_f32(float* agg, int64_t N, const float* W2, const float* b2, const float* W3, const float* b3,
                             const float* n_in, const float* Wl0, const float* bl0, const float* Wl1, const float* bl1,
-                            float* h_out, mpStream_t stream) {
+                            float* h_out, int flags, mpStream_t stream) {
   MP_REQUIRE(N >= 0, "mp_schnet_node_last_f32: bad sizes");
   if (N == 0) return MP_OK;
   MP_REQUIRE(agg && W2 && W3 && n_in && Wl0 && Wl1 && h_out, "mp_schnet_node_last_f32: null pointer");
@@ -336,7 +353,7 @@ int mp_schnet_node_last_f32(float* agg, int64_t N, const float* W2, const float*
   a.N = N;
   a.agg = agg; a.W2 = W2; a.b2 = b2; a.W3 = W3; a.b3 = b3; a.n = const_cast<float*>(n_in);
   a.Wl0 = Wl0; a.bl0 = bl0; a.Wl1 = Wl1; a.bl1 = bl1; a.h = h_out;
-  return launch_node<NODE_LAST, 64>(a, mp::as_stream(stream), "mp_schnet_node_last_f32");
+  return launch_node<NODE_LAST, 64>(a, flags, mp::as_stream(stream), "mp_schnet_node_last_f32");
 }
 
 int mp_schnet_readout_f32(const float* h, const int64_t* node_splits, int64_t G, const float* Wo0, const float* bo0,

@@ -110,6 +110,8 @@ class FusedSchnet:
                   _ffi.stream())
 
     def _launch_all(self):
+        # One linear chain on one stream.  (A two-branch graph - node_in beside edge_prepare - was measured 9 % SLOWER
+        # at config 2: the fork/join costs more than the ~5 us of overlap it buys.)
         p, b = self.p, self._b
         self._prepare()
         if not self.sorted and self.M > 0:
@@ -117,7 +119,8 @@ class FusedSchnet:
                       _ffi.ptr(self.perm), _ffi.ptr(self.sort_ws), self.sort_ws_bytes, _ffi.stream())
         _ffi.call("mp_schnet_node_in_f32", _ffi.ptr(b["z"]), self.N, _ffi.ptr(p["embedding"]),
                   int(p["embedding"].shape[0]), 64, _ffi.ptr(p["dense0/kernel"]), _ffi.ptr(p.get("dense0/bias")),
-                  _ffi.ptr(p["interaction0/dense1/kernel"]), _ffi.ptr(self.n), _ffi.ptr(self.x), _ffi.stream())
+                  _ffi.ptr(p["interaction0/dense1/kernel"]), _ffi.ptr(self.n), _ffi.ptr(self.x), self.flags_arg & 1,
+                  _ffi.stream())
         for i in range(self.depth):
             pre = "interaction%d/" % i
             self._cfconv(i, self.agg)
@@ -125,13 +128,14 @@ class FusedSchnet:
                 _ffi.call("mp_schnet_node_update_f32", _ffi.ptr(self.agg), self.N, _ffi.ptr(p[pre + "dense2/kernel"]),
                           _ffi.ptr(p.get(pre + "dense2/bias")), _ffi.ptr(p[pre + "dense3/kernel"]),
                           _ffi.ptr(p.get(pre + "dense3/bias")), _ffi.ptr(self.n),
-                          _ffi.ptr(p["interaction%d/dense1/kernel" % (i + 1)]), _ffi.ptr(self.x), _ffi.stream())
+                          _ffi.ptr(p["interaction%d/dense1/kernel" % (i + 1)]), _ffi.ptr(self.x), self.flags_arg & 1,
+                          _ffi.stream())
             else:
                 _ffi.call("mp_schnet_node_last_f32", _ffi.ptr(self.agg), self.N, _ffi.ptr(p[pre + "dense2/kernel"]),
                           _ffi.ptr(p.get(pre + "dense2/bias")), _ffi.ptr(p[pre + "dense3/kernel"]),
                           _ffi.ptr(p.get(pre + "dense3/bias")), _ffi.ptr(self.n), _ffi.ptr(p["last_mlp/0/kernel"]),
                           _ffi.ptr(p.get("last_mlp/0/bias")), _ffi.ptr(p["last_mlp/1/kernel"]),
-                          _ffi.ptr(p.get("last_mlp/1/bias")), _ffi.ptr(self.h), _ffi.stream())
+                          _ffi.ptr(p.get("last_mlp/1/bias")), _ffi.ptr(self.h), self.flags_arg & 1, _ffi.stream())
         _ffi.call("mp_schnet_readout_f32", _ffi.ptr(self.h), _ffi.ptr(b["ns"]), self.G,
                   _ffi.ptr(p["output_mlp/0/kernel"]), _ffi.ptr(p.get("output_mlp/0/bias")),
                   _ffi.ptr(p["output_mlp/1/kernel"]), _ffi.ptr(p.get("output_mlp/1/bias")), _ffi.ptr(self.out),

@@ -214,14 +214,16 @@ int mp_cfconv_gauss_diag_f32(const float* x, int64_t N, const float* dist, int b
  * node_in:     n = Embedding(Z) W0 + b0 ; x = n Wx
  * node_update: n += ssp(agg W2 + b2) W3 + b3 ; x = n Wx_next ; agg := 0
  * node_last:   n' = n + ssp(agg W2 + b2) W3 + b3 ; h = ssp(ssp(n' Wl0 + bl0) Wl1 + bl1) (N,64) ; agg := 0
- * readout:     out[g] = ssp(sum_{nodes of g} h W_o0 + b_o0) W_o1 + b_o1   (PoolingNodes(sum) + MLP([64,1])) */
+ * readout:     out[g] = ssp(sum_{nodes of g} h W_o0 + b_o0) W_o1 + b_o1   (PoolingNodes(sum) + MLP([64,1]))
+ * flags bit0: fast softplus as in mp_cfconv_fused_f32. */
 int mp_schnet_node_in_f32(const float* numbers, int64_t N, const float* emb, int vocab, int emb_dim, const float* W0,
-                          const float* b0, const float* Wx, float* n_out, float* x_out, mpStream_t stream);
+                          const float* b0, const float* Wx, float* n_out, float* x_out, int flags, mpStream_t stream);
 int mp_schnet_node_update_f32(float* agg, int64_t N, const float* W2, const float* b2, const float* W3,
-                              const float* b3, float* n_inout, const float* Wx_next, float* x_out, mpStream_t stream);
+                              const float* b3, float* n_inout, const float* Wx_next, float* x_out, int flags,
+                              mpStream_t stream);
 int mp_schnet_node_last_f32(float* agg, int64_t N, const float* W2, const float* b2, const float* W3, const float* b3,
                             const float* n_in, const float* Wl0, const float* bl0, const float* Wl1, const float* bl1,
-                            float* h_out, mpStream_t stream);
+                            float* h_out, int flags, mpStream_t stream);
 int mp_schnet_readout_f32(const float* h, const int64_t* node_splits, int64_t G, const float* Wo0, const float* bo0,
                           const float* Wo1, const float* bo1, float* out, mpStream_t stream);
 
