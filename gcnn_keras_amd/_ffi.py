@@ -47,6 +47,8 @@ _SIGNATURES = {
     "mp_repeat_rows_f32": [P, P, c_int64, c_int64, c_int64, P, P],
     "mp_embedding_f32": [P, c_int64, c_int64, P, c_int64, P, P, P],
     "mp_segment_reduce_csr_f32": [c_int, P, c_int64, c_int64, P, P, c_int64, P, c_int, P, P],
+    "mp_gather_segment_reduce_csr_f32": [c_int, P, c_int64, c_int64, P, c_int64, P, P, c_int64, P, c_int, c_int,
+                                         c_float, P, P],
     "mp_pool_graph_f32": [c_int, P, P, c_int64, c_int64, P, P, P],
     "mp_segment_softmax_csr_f32": [P, c_int64, c_int64, P, P, c_int64, P, P],
     "mp_scatter_relational_f32": [c_int, P, c_int64, c_int64, P, P, c_int64, c_int64, P, P],

@@ -45,7 +45,8 @@ template <int W, typename PtrT>
 __global__ void segment_reduce_csr_kernel(int op, const float* __restrict__ data, int64_t M, int64_t row_elems,
                                           const PtrT* __restrict__ ptr, const int32_t* __restrict__ perm,
                                           int64_t n_out, const float* __restrict__ weight, int normalize,
-                                          float* __restrict__ out) {
+                                          float* __restrict__ out, const int32_t* __restrict__ row_index = nullptr,
+                                          int64_t n_rows = 0, int act = 0, float act_alpha = 0.0f) {
   const int64_t chunks = row_elems / W;
   const int64_t total = n_out * chunks;
   const int64_t stride = static_cast<int64_t>(gridDim.x) * blockDim.x;
@@ -64,7 +65,14 @@ __global__ void segment_reduce_csr_kernel(int op, const float* __restrict__ data
     for (int64_t e = a; e < b; ++e) {
       const int64_t r = perm ? static_cast<int64_t>(perm[e]) : e;
       float v[W];
-      load_vec<W>(base + r * row_elems, v);
+      if (row_index) {
+        // gather-on-read: the row of edge r is x[row_index[r]] (GatherNodesOutgoing fused into the reduce)
+        int64_t src = row_index[r];
+        src = src < 0 ? 0 : (src >= n_rows ? n_rows - 1 : src);
+        load_vec<W>(base + src * row_elems, v);
+      } else {
+        load_vec<W>(base + r * row_elems, v);
+      }
       if (weight) {
         const float w = weight[r];
         wsum += w;
@@ -93,6 +101,10 @@ __global__ void segment_reduce_csr_kernel(int op, const float* __restrict__ data
     if (normalize && weight) {
 #pragma unroll
       for (int i = 0; i < W; ++i) acc[i] = wsum == 0.0f ? 0.0f : acc[i] / wsum;  // tf.math.divide_no_nan
+    }
+    if (act != 0) {
+#pragma unroll
+      for (int i = 0; i < W; ++i) acc[i] = mp_apply_act(act, act_alpha, acc[i]);
     }
     store_vec<W>(out + n * row_elems + c * W, acc);
   }
@@ -189,6 +201,26 @@ int mp_segment_reduce_csr_f32(int op, const float* data, int64_t M, int64_t row_
   MP_REQUIRE(ptr && out && (M == 0 || data), "mp_segment_reduce_csr_f32: null pointer");
   return launch_segment_reduce<int32_t>(op, data, M, row_elems, ptr, perm, N_out, weight, normalize_by_weight, out,
                                         mp::as_stream(stream), "mp_segment_reduce_csr_f32");
+}
+
+int mp_gather_segment_reduce_csr_f32(int op, const float* x, int64_t N, int64_t row_elems, const int32_t* send,
+                                     int64_t M, const int32_t* ptr, const int32_t* perm, int64_t N_out,
+                                     const float* weight, int normalize_by_weight, int act, float act_alpha, float* out,
+                                     mpStream_t stream) {
+  MP_REQUIRE(op >= MP_SUM && op <= MP_MIN, "mp_gather_segment_reduce_csr_f32: unknown op %d", op);
+  MP_REQUIRE(M >= 0 && N >= 0 && N_out >= 0 && row_elems >= 1, "mp_gather_segment_reduce_csr_f32: bad sizes");
+  MP_REQUIRE(act >= MP_ACT_LINEAR && act <= MP_ACT_LEAKY_RELU, "mp_gather_segment_reduce_csr_f32: unknown activation");
+  if (N_out == 0) return MP_OK;
+  MP_REQUIRE(ptr && out && (M == 0 || (x && send && N > 0)), "mp_gather_segment_reduce_csr_f32: null pointer");
+  hipStream_t s = mp::as_stream(stream);
+  if (row_elems % 4 == 0 && aligned16(x) && aligned16(out)) {
+    segment_reduce_csr_kernel<4, int32_t><<<mp::grid_for(N_out * (row_elems / 4)), 256, 0, s>>>(
+        op, x, M, row_elems, ptr, perm, N_out, weight, normalize_by_weight, out, send, N, act, act_alpha);
+  } else {
+    segment_reduce_csr_kernel<1, int32_t><<<mp::grid_for(N_out * row_elems), 256, 0, s>>>(
+        op, x, M, row_elems, ptr, perm, N_out, weight, normalize_by_weight, out, send, N, act, act_alpha);
+  }
+  return mp::check_launch("mp_gather_segment_reduce_csr_f32");
 }
 
 int mp_pool_graph_f32(int op, const float* x, const int64_t* row_splits, int64_t G, int64_t row_elems,

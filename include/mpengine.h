@@ -118,6 +118,14 @@ int mp_segment_reduce_csr_f32(int op, const float* data, int64_t M, int64_t row_
                               const int32_t* perm, int64_t N_out, const float* weight, int normalize_by_weight,
                               float* out, mpStream_t stream);
 
+/* GCN aggregation, kgcnn/layers/conv/gcn_conv.py:87-89 in one pass: GatherNodesOutgoing + PoolingWeightedLocalEdges +
+ * Activation: out[n] = act( op_{e in segment n} weight[e] * x[send[e]] ); the (M,F) gathered rows never exist
+ * (20M + 8NF algorithmic bytes = 125 B/edge at config 5).  send in original edge order, ptr/perm as above. */
+int mp_gather_segment_reduce_csr_f32(int op, const float* x, int64_t N, int64_t row_elems, const int32_t* send,
+                                     int64_t M, const int32_t* ptr, const int32_t* perm, int64_t N_out,
+                                     const float* weight, int normalize_by_weight, int act, float act_alpha, float* out,
+                                     mpStream_t stream);
+
 /* PoolingEmbedding / PoolingNodes, kgcnn/layers/pooling.py:215-218: per-graph reduce driven by int64 row_splits
  * (value_rowids never materialised).  Writes G rows (the host trims trailing empty graphs like TF does). */
 int mp_pool_graph_f32(int op, const float* x, const int64_t* row_splits, int64_t G, int64_t row_elems,

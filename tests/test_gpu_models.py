@@ -123,3 +123,26 @@ def test_message_passing_base():
     ref = ko.lazy_add([n, ko.pooling_local_edges(n, msg, ei, "sum")])
     assert np.max(np.abs(out.values.cpu().numpy() - ref.values)) <= 1e-5 * np.max(np.abs(ref.values))
     assert lay.get_config()["pooling_method"] == "sum"
+
+
+@pytest.mark.parametrize("method,normalize,act", [("sum", False, "relu"), ("mean", False, "linear"),
+                                                   ("sum", True, "kgcnn>leaky_relu"), ("max", False, "relu")])
+def test_gcn_layer_fused_aggregate_equals_layer_sequence(method, normalize, act):
+    """GCN.call's fused gather+weighted-pool+activation kernel vs the oracle's layer sequence (gcn_conv.py:85-90),
+    on an unsorted edge list."""
+    from gcnn_keras_amd.layers.conv.gcn_conv import GCN
+    g = synth.cora_like_graph(num_nodes=90, num_features=24, seed=3, drop_pairs=5)
+    rng = np.random.default_rng(0)
+    perm = rng.permutation(len(g["edge_indices"]))
+    ei, ew = g["edge_indices"][perm], g["edge_weights"][perm]
+    k, bias = synth.glorot_uniform(rng, 24, 32), rng.uniform(-.1, .1, 32).astype(np.float32)
+    lay = GCN(units=32, pooling_method=method, normalize_by_weights=normalize, activation=act)
+    lay.ensure_built([(None, None, 24), (None, None, 1), (None, None, 2)])
+    lay.set_weights([k, bias])
+    out = lay([_dev(g["node_attributes"], g["node_splits"]), _dev(ew, g["edge_splits"]), _dev(ei, g["edge_splits"])])
+    ref = ko.gcn_layer(ko.R(g["node_attributes"], g["node_splits"]), ko.R(ew, g["edge_splits"]),
+                       ko.R(ei, g["edge_splits"]), {"kernel": k, "bias": bias}, act=act, pooling_method=method,
+                       normalize_by_weights=normalize)
+    got = out.values.cpu().numpy()
+    assert got.shape == ref.values.shape
+    assert np.max(np.abs(got - ref.values)) <= 1e-5 * max(np.max(np.abs(ref.values)), 1e-30)
