@@ -9,22 +9,43 @@
 
 namespace {
 
+// Four independent (index -> row -> store) chains per thread and iteration: a single dependent chain per wave leaves
+// the memory system latency-bound (3.3 TB/s measured); with four in flight the copy streams.
 template <typename VecT>
 __global__ void gather_cols_kernel(const VecT* __restrict__ x, int64_t N, int64_t chunks,
                                    const int32_t* __restrict__ cols, int64_t M, int ncols, int c0, int c1, int c2,
                                    int c3, VecT* __restrict__ out) {
+  constexpr int U = 4;
   const int64_t total = M * ncols * chunks;
   const int64_t stride = static_cast<int64_t>(gridDim.x) * blockDim.x;
-  for (int64_t t = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x; t < total; t += stride) {
-    const int64_t c = t % chunks;
-    const int64_t ec = t / chunks;
-    const int k = static_cast<int>(ec % ncols);
-    const int64_t e = ec / ncols;
-    const int sel = k == 0 ? c0 : (k == 1 ? c1 : (k == 2 ? c2 : c3));
-    const int64_t row = cols[static_cast<int64_t>(sel) * M + e];
-    VecT v{};
-    if (row >= 0 && row < N) v = x[row * chunks + c];
-    out[t] = v;
+  for (int64_t t0 = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x; t0 < total; t0 += U * stride) {
+    int64_t row[U];
+    int64_t cc[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int64_t t = t0 + u * stride;
+      row[u] = -1;
+      cc[u] = 0;
+      if (t < total) {
+        cc[u] = t % chunks;
+        const int64_t ec = t / chunks;
+        const int k = static_cast<int>(ec % ncols);
+        const int64_t e = ec / ncols;
+        const int sel = k == 0 ? c0 : (k == 1 ? c1 : (k == 2 ? c2 : c3));
+        row[u] = cols[static_cast<int64_t>(sel) * M + e];
+      }
+    }
+    VecT v[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      v[u] = VecT{};
+      if (row[u] >= 0 && row[u] < N) v[u] = x[row[u] * chunks + cc[u]];
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int64_t t = t0 + u * stride;
+      if (t < total) out[t] = v[u];
+    }
   }
 }
 

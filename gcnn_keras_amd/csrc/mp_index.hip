@@ -44,8 +44,13 @@ __global__ void index_prepare_kernel(const int64_t* __restrict__ idx, int64_t M,
                                      int32_t* __restrict__ cols, int32_t* __restrict__ flags) {
   const int64_t stride = static_cast<int64_t>(gridDim.x) * blockDim.x;
   int local_flags = 0;
-  for (int64_t e = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x; e < M; e += stride) {
-    const int64_t g = owner_of(edge_splits, G, e);
+  for (int64_t e = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x; e - (threadIdx.x & 63) < M;
+       e += stride) {
+    // one wave-uniform owner search (scalar loads) for the wave's first edge, then a short per-lane walk
+    const int64_t e_wave = __builtin_amdgcn_readfirstlane(static_cast<int>(e - (threadIdx.x & 63)));
+    int64_t g = owner_of(edge_splits, G, e_wave < M ? e_wave : M - 1);
+    if (e >= M) continue;
+    while (g + 1 < G && edge_splits[g + 1] <= e) ++g;
     const int64_t base = node_splits[g];
     const int64_t n_g = node_splits[g + 1] - base;
     // shift of the previous edge (for the sortedness check of the batch-level ids)

@@ -15,13 +15,6 @@
 
 namespace {
 
-struct F1 { float v[1]; };
-struct F4 { float v[4]; };
-
-template <int W> struct VecOf;
-template <> struct VecOf<1> { using type = float; };
-template <> struct VecOf<4> { using type = float4; };
-
 template <int W>
 __device__ __forceinline__ void load_vec(const float* p, float (&v)[W]) {
   if constexpr (W == 4) {
@@ -62,35 +55,47 @@ __global__ void segment_reduce_csr_kernel(int op, const float* __restrict__ data
     for (int i = 0; i < W; ++i) acc[i] = 0.0f;
     float wsum = 0.0f;
     const float* base = data + c * W;
-    for (int64_t e = a; e < b; ++e) {
-      const int64_t r = perm ? static_cast<int64_t>(perm[e]) : e;
-      float v[W];
-      if (row_index) {
-        // gather-on-read: the row of edge r is x[row_index[r]] (GatherNodesOutgoing fused into the reduce)
-        int64_t src = row_index[r];
-        src = src < 0 ? 0 : (src >= n_rows ? n_rows - 1 : src);
-        load_vec<W>(base + src * row_elems, v);
-      } else {
-        load_vec<W>(base + r * row_elems, v);
+    // rows are fetched four at a time (independent loads in flight), then folded in edge order
+    for (int64_t e0 = a; e0 < b; e0 += 4) {
+      float v[4][W];
+      float wv[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        wv[u] = 1.0f;
+        if (e0 + u < b) {
+          const int64_t r = perm ? static_cast<int64_t>(perm[e0 + u]) : (e0 + u);
+          int64_t src = r;
+          if (row_index) {
+            // gather-on-read: the row of edge r is x[row_index[r]] (GatherNodesOutgoing fused into the reduce)
+            src = row_index[r];
+            src = src < 0 ? 0 : (src >= n_rows ? n_rows - 1 : src);
+          }
+          load_vec<W>(base + src * row_elems, v[u]);
+          if (weight) wv[u] = weight[r];
+        }
       }
-      if (weight) {
-        const float w = weight[r];
-        wsum += w;
 #pragma unroll
-        for (int i = 0; i < W; ++i) v[i] *= w;
-      }
-      if (e == a) {
+      for (int u = 0; u < 4; ++u) {
+        if (e0 + u < b) {
+          if (weight) {
+            wsum += wv[u];
 #pragma unroll
-        for (int i = 0; i < W; ++i) acc[i] = v[i];
-      } else if (op == MP_MAX) {
+            for (int i = 0; i < W; ++i) v[u][i] *= wv[u];
+          }
+          if (e0 + u == a) {
 #pragma unroll
-        for (int i = 0; i < W; ++i) acc[i] = fmaxf(acc[i], v[i]);
-      } else if (op == MP_MIN) {
+            for (int i = 0; i < W; ++i) acc[i] = v[u][i];
+          } else if (op == MP_MAX) {
 #pragma unroll
-        for (int i = 0; i < W; ++i) acc[i] = fminf(acc[i], v[i]);
-      } else {
+            for (int i = 0; i < W; ++i) acc[i] = fmaxf(acc[i], v[u][i]);
+          } else if (op == MP_MIN) {
 #pragma unroll
-        for (int i = 0; i < W; ++i) acc[i] += v[i];
+            for (int i = 0; i < W; ++i) acc[i] = fminf(acc[i], v[u][i]);
+          } else {
+#pragma unroll
+            for (int i = 0; i < W; ++i) acc[i] += v[u][i];
+          }
+        }
       }
     }
     if (op == MP_MEAN && b > a) {
