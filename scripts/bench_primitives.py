@@ -67,6 +67,13 @@ def main():
     ms = timer.time_ms(lambda: pm(inp), 10)
     print("\nPaiNN forward (config 3: 64 graphs, N=%d, M=%d), layer path: %.2f ms = %.1f M edges/s"
           % (bp["node_splits"][-1], bp["edge_splits"][-1], ms, bp["edge_splits"][-1] / ms / 1e3))
+    from gcnn_keras_amd.engine import GraphedModel
+    gp = GraphedModel(pm, inp)
+    ref = pm(inp).cpu().numpy()
+    assert np.max(np.abs(gp().cpu().numpy() - ref)) <= 1e-6 * np.max(np.abs(ref))
+    ms = timer.time_ms(lambda: gp(), 20)
+    print("PaiNN forward, same layer path replayed from one HIP graph (GraphedModel): %.3f ms = %.1f M edges/s"
+          % (ms, bp["edge_splits"][-1] / ms / 1e3))
     efm = EnergyForceModel(model_energy=pm, energy_output=0, output_squeeze_states=True)
     ms = timer.time_ms(lambda: efm(inp), 5)
     print("PaiNN energy + force (EnergyForceModel), layer path forward + reverse: %.2f ms" % ms)
@@ -82,6 +89,9 @@ def main():
             RaggedTensor.from_numpy(g["edge_weights"], g["edge_splits"]),
             RaggedTensor.from_numpy(g["edge_indices"], g["edge_splits"])]
     ms = timer.time_ms(lambda: gm(ginp), 10)
+    gg = GraphedModel(gm, ginp)
+    ms_g = timer.time_ms(lambda: gg(), 20)
+    print("GCN forward replayed from one HIP graph: %.3f ms = %.1f M edges/s" % (ms_g, g["edge_splits"][-1] / ms_g / 1e3))
     deg = np.bincount(g["edge_indices"][:, 0]).max()
     print("GCN forward (config 5: N=2708, M=%d incl. self loops, max in-degree %d), layer path: %.3f ms = %.1f M edges/s"
           % (g["edge_splits"][-1], deg, ms, g["edge_splits"][-1] / ms / 1e3))
