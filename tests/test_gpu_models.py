@@ -146,3 +146,22 @@ def test_gcn_layer_fused_aggregate_equals_layer_sequence(method, normalize, act)
     got = out.values.cpu().numpy()
     assert got.shape == ref.values.shape
     assert np.max(np.abs(got - ref.values)) <= 1e-5 * max(np.max(np.abs(ref.values)), 1e-30)
+
+
+def test_graphed_model_replay_matches_eager():
+    """engine.GraphedModel: the layer path captured once into a HIP graph replays to the same numbers, and follows
+    in-place updates of the input values."""
+    from gcnn_keras_amd.engine import GraphedModel
+    from gcnn_keras_amd.literature import Schnet
+    b = synth.qm9_like_batch(num_graphs=5, seed=31)
+    p = synth.schnet_params(seed=7, random_bias=True)
+    model = Schnet.make_model(depth=2)
+    model.set_weights(list(synth.schnet_params(seed=7, depth=2, random_bias=True).values()))
+    inputs = [_dev(b["node_number"], b["node_splits"]), _dev(b["node_coordinates"], b["node_splits"]),
+              _dev(b["edge_indices"], b["edge_splits"])]
+    eager = model(inputs).cpu().numpy()
+    gm = GraphedModel(model, inputs)
+    assert np.array_equal(gm().cpu().numpy(), eager)
+    inputs[1].values.mul_(1.01)          # new coordinates, same topology
+    assert np.array_equal(gm().cpu().numpy(), model(inputs).cpu().numpy())
+    assert not np.array_equal(gm().cpu().numpy(), eager)
