@@ -117,16 +117,31 @@ __global__ __launch_bounds__(WAVES * 64) void cfconv_fused_kernel(CfconvArgs a) 
   };
   prefetch_tile(tile_first);
 
-  // ---- stage the pre-packed weights once per workgroup: a straight 16-byte copy into the LDS image ---------------
+  // ---- stage the pre-packed weights once per workgroup.  The small W1 image (17 KB) goes through registers and is
+  //      published by the first barrier - GEMM1 needs nothing else.  The 64 KB of W2 follow by LDS-DMA
+  //      (global_load_lds_dwordx4: 1 KB per wave instruction, no VGPRs), issued after that barrier so that no ordinary
+  //      load is pending beside them, and are awaited only right before the first GEMM2: their flight hides under the
+  //      first tile's sender-row loads, Gauss basis, GEMM1 and softplus. -----------------------------------------------
   {
     const float4* src = reinterpret_cast<const float4*>(a.packed);
     float4* dst = reinterpret_cast<float4*>(lds);
-    for (int i = tid; i < (MAX_KROWS * F + F * F) / 4; i += WAVES * 64) dst[i] = src[i];
+    for (int i = tid; i < (MAX_KROWS * F) / 4; i += WAVES * 64) dst[i] = src[i];
   }
   float bias2[4];
 #pragma unroll
   for (int jb = 0; jb < 4; ++jb) bias2[jb] = a.packed[MAX_KROWS * F + F * F + jb * 32 + c];
   __syncthreads();
+  {
+    constexpr int CHUNKS_PER_WAVE = (F * F / 256) / WAVES;  // 1-KB chunks of the W2 image per wave
+    const float* src = a.packed + MAX_KROWS * F;
+#pragma unroll
+    for (int i = 0; i < CHUNKS_PER_WAVE; ++i) {
+      const int chunk = wave * CHUNKS_PER_WAVE + i;
+      __builtin_amdgcn_global_load_lds(src + chunk * 256 + lane * 4,
+                                       (__attribute__((address_space(3))) void*)(W2s + chunk * 256), 16, 0, 0);
+    }
+  }
+  bool w2_ready = false;  // wave-uniform: every wave passes the publishing barrier exactly once
 
   MP_STAMP(0)
   float* T = Ts + wave * ((WAVES > 4 ? F / 2 : F) * T_LD);
@@ -211,6 +226,10 @@ __global__ __launch_bounds__(WAVES * 64) void cfconv_fused_kernel(CfconvArgs a) 
 #pragma unroll
       for (int r = 0; r < 16; ++r) h[ib][r] = FAST_SSP ? ssp_fast(h[ib][r]) : ssp_exact(h[ib][r]);
 
+    if (!w2_ready) {
+      __syncthreads();  // drains this wave's LDS-DMA (vmcnt) and publishes all four waves' parts of W2
+      w2_ready = true;
+    }
     MP_STAMP(3)
     // ---- GEMM2: w[e][j] = sum_f h[e][f] W2[f][j] + b2[j]; A = the accumulator registers of GEMM1 ------------
     floatx16 w[4];
@@ -300,6 +319,7 @@ __global__ __launch_bounds__(WAVES * 64) void cfconv_fused_kernel(CfconvArgs a) 
     }
     MP_STAMP(7)
   }
+  if (!w2_ready) __syncthreads();  // a wave without tiles still owes the workgroup its barrier
   if constexpr (DIAG) {
     if (lane == 0 && a.diag) {
 #pragma unroll
