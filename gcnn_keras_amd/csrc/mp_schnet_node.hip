@@ -105,12 +105,69 @@ enum NodeMode { NODE_IN = 0, NODE_MID = 1, NODE_LAST = 2 };
 
 template <int MODE, int E, int RB, bool FAST>
 __global__ __launch_bounds__(256, (RB == 4 && MODE != NODE_LAST) ? 2 : 1) void schnet_node_kernel(NodeArgs a) {
-  constexpr int TN = 16 * RB;  // nodes per tile
-  __shared__ float Xa[TN * X_LD];
-  __shared__ float Xb[TN * X_LD];
+  __shared__ float Xa[16 * RB * X_LD];
+  __shared__ float Xb[16 * RB * X_LD];
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = tid >> 6;
+
+  // ---- input-tile staging through registers.  In the 16-node (latency-bound) build the first tile's rows are
+  //      requested BEFORE the weight slices (vmcnt retires in order: the tile must not queue behind 192 weight loads)
+  //      and the next tile's rows are requested while the current tile computes. ------------------------------------
+  constexpr int TN = 16 * RB;
+  constexpr bool EARLY_STAGE = RB == 1;
+  constexpr int SV_IN = (TN * E) / 256;      // floats per thread (NODE_IN: embedding rows)
+  constexpr int SV = (TN * F / 4) / 256;     // float4 per thread (aggregation rows)
+  float stg_in[MODE == NODE_IN ? SV_IN : 1];
+  float4 stg[MODE == NODE_IN ? 1 : SV];
+  auto stage_load = [&](int t) {
+    const int64_t n0 = static_cast<int64_t>(t) * TN;
+    if constexpr (MODE == NODE_IN) {
+#pragma unroll
+      for (int j = 0; j < SV_IN; ++j) {
+        const int i = tid + j * 256;
+        const int r = i / E, k = i % E;
+        const int64_t node = n0 + r;
+        float v = 0.0f;
+        if (t < a.ntiles && node < a.N) {
+          const int z = static_cast<int>(a.numbers[node]);  // Keras Embedding casts float input to int32
+          if (z >= 0 && z < a.vocab) v = a.emb[static_cast<int64_t>(z) * E + k];
+        }
+        stg_in[j] = v;
+      }
+    } else {
+#pragma unroll
+      for (int j = 0; j < SV; ++j) {
+        const int i = tid + j * 256;
+        const int r = i / (F / 4), k4 = i % (F / 4);
+        const int64_t node = n0 + r;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (t < a.ntiles && node < a.N) {
+          float4* p = reinterpret_cast<float4*>(a.agg + node * F) + k4;
+          v = *p;
+          *p = make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+        stg[j] = v;
+      }
+    }
+  };
+  auto stage_store = [&]() {
+    if constexpr (MODE == NODE_IN) {
+#pragma unroll
+      for (int j = 0; j < SV_IN; ++j) {
+        const int i = tid + j * 256;
+        Xa[(i / E) * X_LD + (i % E)] = stg_in[j];
+      }
+    } else {
+#pragma unroll
+      for (int j = 0; j < SV; ++j) {
+        const int i = tid + j * 256;
+        float* d = Xa + (i / (F / 4)) * X_LD + 4 * (i % (F / 4));
+        d[0] = stg[j].x; d[1] = stg[j].y; d[2] = stg[j].z; d[3] = stg[j].w;
+      }
+    }
+  };
+  if constexpr (EARLY_STAGE) stage_load(blockIdx.x);
 
   // ---- weight slices -> registers (once per persistent workgroup) -------------------------------------------
   float w_first[2][(MODE == NODE_IN ? E : F) / 4];   // IN: W0 ; MID/LAST: W2
@@ -148,34 +205,16 @@ __global__ __launch_bounds__(256, (RB == 4 && MODE != NODE_LAST) ? 2 : 1) void s
   for (int tile = blockIdx.x; tile < a.ntiles; tile += gridDim.x) {
     const int64_t node0 = static_cast<int64_t>(tile) * TN;
 
-    // ---- stage the input tile into Xa (coalesced), re-zero the consumed aggregation rows ---------------------
-    if constexpr (MODE == NODE_IN) {
-      for (int i = tid; i < TN * E; i += 256) {
-        const int r = i / E, k = i % E;
-        const int64_t node = node0 + r;
-        float v = 0.0f;
-        if (node < a.N) {
-          const int z = static_cast<int>(a.numbers[node]);  // Keras Embedding casts float input to int32
-          if (z >= 0 && z < a.vocab) v = a.emb[static_cast<int64_t>(z) * E + k];
-        }
-        Xa[r * X_LD + k] = v;
-      }
+    // ---- stage the input tile into Xa (coalesced; the consumed aggregation rows were re-zeroed by stage_load) --------
+    if constexpr (EARLY_STAGE) {
+      stage_store();
     } else {
-      for (int i = tid; i < TN * F / 4; i += 256) {
-        const int r = i / (F / 4), k4 = i % (F / 4);
-        const int64_t node = node0 + r;
-        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (node < a.N) {
-          float4* p = reinterpret_cast<float4*>(a.agg + node * F) + k4;
-          v = *p;
-          *p = make_float4(0.f, 0.f, 0.f, 0.f);
-        }
-        float* d = Xa + r * X_LD + 4 * k4;
-        d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
-      }
+      stage_load(tile);
+      stage_store();
     }
     __syncthreads();
 
+    if constexpr (EARLY_STAGE) stage_load(tile + static_cast<int>(gridDim.x));  // next tile, in flight during the GEMMs
     floatx4 acc[RB][2];
     // residual rows of n, requested now so that the round trip hides under GEMM 1 and 2
     constexpr bool PREFETCH_N = RB == 1;  // the 64-node build spends its registers on two workgroups per CU instead
