@@ -91,6 +91,9 @@ class PAiNNconv(GraphBaseLayer):
         node, equivariant, rbf, envelope, r_ij, indexlist = inputs
         s = self.lay_dense1(node)
         s = self.lay_phi(s)
+        fused = self._fused_message(node, s, equivariant, rbf, envelope, r_ij, indexlist)
+        if fused is not None:
+            return fused
         s = self.gather_n([s, indexlist])
         w = self.lay_w(rbf)
         if self.cutoff is not None:
@@ -107,6 +110,31 @@ class PAiNNconv(GraphBaseLayer):
         dv = self.lay_add([dv1, dv2])
         dv = self.lay_sum_v([node, dv, indexlist])
         return ds, dv
+
+    def _fused_message(self, node, s, equivariant, rbf, envelope, r_ij, indexlist):
+        """Edge side of the block in one kernel (``mp_painn_message_fused_f32``) when the configuration allows:
+        128 units, sum pooling, basis <= 32, no gradient requested (forces use the layer sequence)."""
+        from ... import _ffi
+        from ...autograd import needs_grad
+        if (self.units != 128 or self.conv_pool not in ("sum", "segment_sum", "reduce_sum")
+                or int(rbf.values.shape[-1]) > 32 or rbf.values.dim() != 2 or equivariant.values.dim() != 3
+                or int(equivariant.values.shape[1]) != 3
+                or needs_grad(s.values, equivariant.values, rbf.values, r_ij.values, envelope.values)):
+            return None
+        plan = indexlist.index_plan(node)
+        pool = self.lay_sum
+        if pool.pooling_index != 0 or not pool.has_unconnected:
+            return None
+        ptr, perm, _ = plan.csr(0, assume_sorted=pool.is_sorted)
+        sv, vv = s.values.contiguous(), equivariant.values.contiguous()
+        ds = torch.empty((plan.N, 128), dtype=torch.float32, device=sv.device)
+        dv = torch.empty((plan.N, 3, 128), dtype=torch.float32, device=sv.device)
+        env = envelope.values.contiguous().view(-1) if self.cutoff is not None else None
+        _ffi.call("mp_painn_message_fused_f32", _ffi.ptr(sv), _ffi.ptr(vv), plan.N, _ffi.ptr(rbf.values.contiguous()),
+                  int(rbf.values.shape[-1]), _ffi.ptr(env), _ffi.ptr(r_ij.values.contiguous()),
+                  _ffi.ptr(self.lay_w.kernel), _ffi.ptr(self.lay_w.bias), _ffi.ptr(ptr), _ffi.ptr(perm),
+                  _ffi.ptr(plan.col(1).contiguous()), plan.M, _ffi.ptr(ds), _ffi.ptr(dv), _ffi.stream())
+        return node.with_values(ds), equivariant.with_values(dv)
 
     def get_config(self):
         config = super().get_config()

@@ -218,6 +218,15 @@ int mp_cfconv_gauss_diag_f32(const float* x, int64_t N, const float* dist, int b
                              const int32_t* perm, int64_t M, float* out_zeroed, unsigned long long* diag8,
                              mpStream_t stream);
 
+/* PAiNNconv.call edge side, kgcnn/layers/conv/painn_conv.py:99-113, fused (F = units = 128, conv_pool = sum):
+ * w = rbf Ww + bw [* env]; sw = s[send] * w; ds[i] = sum sw1; dv[i] = sum (sw2 (x) v[send] + sw3 (x) r_ij) over the edges
+ * of receiver i in edge order (CSR ptr / perm as mp_segment_reduce_csr_f32).  s (N,3F) = phi(dense1(z)), v (N,3,F),
+ * rbf (M,B<=32), env (M)|NULL, rij (M,3), Ww (B,3F), bw (3F)|NULL; writes ds (N,F), dv (N,3,F) incl. zero rows. */
+int mp_painn_message_fused_f32(const float* s, const float* v, int64_t N, const float* rbf, int B, const float* env,
+                               const float* rij, const float* Ww, const float* bw, const int32_t* ptr,
+                               const int32_t* perm, const int32_t* send, int64_t M, float* ds, float* dv,
+                               mpStream_t stream);
+
 /* Node-side chains of kgcnn/literature/Schnet.py:110-133 / schnet_conv.py:159-165 (F = 128, embedding width 64):
  * node_in:     n = Embedding(Z) W0 + b0 ; x = n Wx
  * node_update: n += ssp(agg W2 + b2) W3 + b3 ; x = n Wx_next ; agg := 0

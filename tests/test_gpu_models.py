@@ -165,3 +165,38 @@ def test_graphed_model_replay_matches_eager():
     inputs[1].values.mul_(1.01)          # new coordinates, same topology
     assert np.array_equal(gm().cpu().numpy(), model(inputs).cpu().numpy())
     assert not np.array_equal(gm().cpu().numpy(), eager)
+
+
+@pytest.mark.parametrize("cutoff,shuffle", [(None, False), (5.0, True)])
+def test_painn_conv_fused_message_vs_oracle(cutoff, shuffle):
+    """PAiNNconv.call with the fused edge kernel vs the oracle's layer sequence (painn_conv.py:97-115)."""
+    from gcnn_keras_amd.layers.conv.painn_conv import PAiNNconv
+    b = synth.md17_like_batch(num_graphs=3, seed=4)
+    rng = np.random.default_rng(1)
+    idx = b["edge_indices"].copy()
+    if shuffle:
+        for g in range(3):
+            lo, hi = b["edge_splits"][g], b["edge_splits"][g + 1]
+            idx[lo:hi] = idx[lo:hi][rng.permutation(hi - lo)]
+    n, m = int(b["node_splits"][-1]), int(b["edge_splits"][-1])
+    z = ko.R(rng.normal(size=(n, 128)).astype(np.float32), b["node_splits"])
+    v = ko.R(rng.normal(size=(n, 3, 128)).astype(np.float32), b["node_splits"])
+    ridx = ko.R(idx, b["edge_splits"])
+    xyz = ko.R(b["node_coordinates"], b["node_splits"])
+    p1, p2 = ko.node_position(xyz, ridx)
+    d = ko.node_distance_euclidean(p1, p2)
+    rij = ko.edge_direction_normalized(p1, p2)
+    rbf = ko.bessel_basis(d, 20, 5.0)
+    env = ko.cos_cutoff_envelope(d, cutoff)
+    p = {k[len("conv0/"):]: v_ for k, v_ in synth.painn_params(seed=8, random_bias=True).items()
+         if k.startswith("conv0/")}
+    lay = PAiNNconv(units=128, cutoff=cutoff)
+    lay.ensure_built([(None, None, 128), (None, None, 3, 128), (None, None, 20), (None, None, 1), (None, None, 3),
+                      (None, None, 2)])
+    lay.set_weights([p["dense1/kernel"], p["dense1/bias"], p["phi/kernel"], p["phi/bias"], p["w/kernel"], p["w/bias"]])
+    ds, dv = lay([_dev(z.values, z.row_splits), _dev(v.values, v.row_splits), _dev(rbf.values, rbf.row_splits),
+                  _dev(env.values, env.row_splits), _dev(rij.values, rij.row_splits), _dev(idx, b["edge_splits"])])
+    rds, rdv = ko.painn_conv(z, v, rbf, env, rij, ridx, p, cutoff=cutoff)
+    for got, ref in ((ds.values.cpu().numpy(), rds.values), (dv.values.cpu().numpy(), rdv.values)):
+        assert got.shape == ref.shape
+        assert np.max(np.abs(got - ref)) <= 1e-5 * np.max(np.abs(ref))
