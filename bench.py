@@ -108,6 +108,8 @@ def main():
     ap.add_argument("--graphs", type=int, default=128, help="graphs per GPU (BASELINE config 2 = 128)")
     ap.add_argument("--mode", default="auto", choices=["auto", "fused", "layers"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
+                    help="nccl = RCCL over xGMI (production); gloo only rehearses N > 1 on a single-GPU box")
     args = ap.parse_args()
 
     import torch
@@ -120,12 +122,18 @@ def main():
     if world != args.gpus:
         raise SystemExit("--gpus %d but WORLD_SIZE=%d: launch with torch.distributed.run --nproc-per-node %d"
                          % (args.gpus, world, args.gpus))
-    torch.cuda.set_device(local_rank)
+    ndev = torch.cuda.device_count()
+    device_index = local_rank % max(ndev, 1)  # one rank per GPU on a full node; wraps only in single-GPU rehearsals
+    torch.cuda.set_device(device_index)
     dist = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world,
+                                    device_id=torch.device("cuda", device_index))
+        else:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
 
     depth = 3
     batch = synth.qm9_like_batch(num_graphs=args.graphs, seed=1234 + rank)
@@ -136,11 +144,22 @@ def main():
     fwd.load_batch(batch)
     gathered = torch.empty((world * n_graphs, 1), dtype=torch.float32, device="cuda") if world > 1 else None
 
+    host_parts = [torch.empty((n_graphs, 1)) for _ in range(world)] if (world > 1 and args.backend == "gloo") else None
+
     def step():
         out = fwd.forward()
         if world > 1:
-            dist.all_gather_into_tensor(gathered, out)
+            if host_parts is None:
+                dist.all_gather_into_tensor(gathered, out)       # RCCL, on the forward's stream
+            else:
+                dist.all_gather(host_parts, out.cpu())             # rehearsal only
         return out
+
+    def reduce_scalar(value, op):
+        t = torch.tensor([value], dtype=torch.float64, device="cuda" if args.backend == "nccl" else "cpu")
+        if world > 1:
+            dist.all_reduce(t, op=op)
+        return float(t.item())
 
     with torch.cuda.stream(fwd.stream):  # one stream for graph replay and the collective: no cross-stream events
         for _ in range(args.warmup):
@@ -157,13 +176,8 @@ def main():
         dist.barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
-    t_max = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
-    edges_all = torch.tensor([n_edges], dtype=torch.float64, device="cuda")
-    if world > 1:
-        dist.all_reduce(t_max, op=dist.ReduceOp.MAX)
-        dist.all_reduce(edges_all, op=dist.ReduceOp.SUM)
-    elapsed = float(t_max.item())
-    total_edges = float(edges_all.item())
+    elapsed = reduce_scalar(elapsed, dist.ReduceOp.MAX if world > 1 else None)
+    total_edges = reduce_scalar(float(n_edges), dist.ReduceOp.SUM if world > 1 else None)
 
     fwd.check_flags()
     roof = fwd.roofline(HBM_PEAK_GBS, FP32_MFMA_PEAK_TF)  # dominant kernel, timed with HIP events on its stream
