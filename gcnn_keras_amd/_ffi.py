@@ -72,6 +72,8 @@ _SIGNATURES = {
     "mp_cfconv_gauss_diag_f32": [P, c_int64, P, c_int, c_float, c_float, c_float, P, P, P, P, c_int64, P, P, P],
     "mp_painn_message_fused_f32": [P, P, c_int64, P, c_int, P, P, P, P, P, P, P, c_int64, P, P, P],
     "mp_schnet_node_in_f32": [P, c_int64, P, c_int, c_int, P, P, P, P, P, c_int, P],
+    "mp_schnet_stage0_f32": [P, c_int64, P, c_int, c_int, P, P, P, P, P, P, c_int64, P, P, c_int64, P, P, P, P, P, c_int,
+                             P],
     "mp_schnet_node_update_f32": [P, c_int64, P, P, P, P, P, P, P, c_int, P],
     "mp_schnet_node_last_f32": [P, c_int64, P, P, P, P, P, P, P, P, P, P, c_int, P],
     "mp_schnet_readout_f32": [P, P, c_int64, P, P, P, P, P, P],

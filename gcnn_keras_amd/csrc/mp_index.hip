@@ -9,6 +9,7 @@
 #include <rocprim/rocprim.hpp>
 
 #include "mp_common.h"
+#include "mp_edge_prepare.h"
 
 namespace {
 
@@ -91,82 +92,9 @@ __global__ void csr_from_sorted_kernel(const int32_t* __restrict__ seg, int64_t 
 // index_prepare (K = 2) fused with the geometry pre-step NodePosition -> LazySubtract -> EuclideanNorm
 // (kgcnn/literature/Schnet.py:116-117): one pass over the (M,2) int64 rows yields receiver / sender ids and the
 // edge distance the Gauss expansion starts from.
-// owner search on a staged (LDS) copy of the splits
-__device__ __forceinline__ int owner_of_lds(const int64_t* splits, int G, int64_t e) {
-  int lo = 0, hi = G;
-  while (hi - lo > 1) {
-    const int mid = (lo + hi) >> 1;
-    if (splits[mid] <= e) lo = mid; else hi = mid;
-  }
-  return lo;
-}
-
-constexpr int PREP_LDS_GRAPHS = 1023;  // batches up to this many graphs search their row_splits in LDS
-
-// LDS_SPLITS: every workgroup first copies both row_splits arrays (G+1 <= 1024 entries each) into LDS with one
-// coalesced round trip; the per-edge owner search then never leaves the CU.  At QM9 batch sizes this kernel is a chain
-// of dependent round trips (search steps -> offsets -> index row -> coordinates), so removing the ~7 search trips is
-// what matters.  Larger batches search the L2-resident arrays directly (one wave-uniform search + a short walk).
 template <bool LDS_SPLITS>
-__global__ __launch_bounds__(256) void edge_prepare_kernel(const int64_t* __restrict__ idx, int64_t M,
-                                                           const int64_t* __restrict__ node_splits,
-                                                           const int64_t* __restrict__ edge_splits, int64_t G,
-                                                           int64_t N, const float* __restrict__ xyz,
-                                                           int32_t* __restrict__ recv, int32_t* __restrict__ send,
-                                                           float* __restrict__ dist, int32_t* __restrict__ flags) {
-  __shared__ int64_t s_es[LDS_SPLITS ? PREP_LDS_GRAPHS + 1 : 1];
-  __shared__ int64_t s_ns[LDS_SPLITS ? PREP_LDS_GRAPHS + 1 : 1];
-  if constexpr (LDS_SPLITS) {
-    for (int i = threadIdx.x; i <= G; i += blockDim.x) {
-      s_es[i] = edge_splits[i];
-      s_ns[i] = node_splits[i];
-    }
-    __syncthreads();
-  }
-  const int64_t stride = static_cast<int64_t>(gridDim.x) * blockDim.x;
-  int local_flags = 0;
-  for (int64_t e = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x; e - (threadIdx.x & 63) < M;
-       e += stride) {
-    int64_t g, base, n_g, g_start;
-    if constexpr (LDS_SPLITS) {
-      if (e >= M) continue;
-      g = owner_of_lds(s_es, static_cast<int>(G), e);
-      base = s_ns[g];
-      n_g = s_ns[g + 1] - base;
-      g_start = s_es[g];
-    } else {
-      const int64_t e_wave = __builtin_amdgcn_readfirstlane(static_cast<int>(e - (threadIdx.x & 63)));
-      g = owner_of(edge_splits, G, e_wave < M ? e_wave : M - 1);
-      if (e >= M) continue;
-      while (g + 1 < G && edge_splits[g + 1] <= e) ++g;
-      base = node_splits[g];
-      n_g = node_splits[g + 1] - base;
-      g_start = edge_splits[g];
-    }
-    const longlong2 v = reinterpret_cast<const longlong2*>(idx)[e];
-    int64_t i = v.x, j = v.y;
-    if (i < 0 || i >= n_g || j < 0 || j >= n_g) {
-      local_flags |= MP_FLAG_OOB;
-      const int64_t hi = n_g > 0 ? n_g - 1 : 0;
-      i = i < 0 ? 0 : (i > hi ? hi : i);
-      j = j < 0 ? 0 : (j > hi ? hi : j);
-    }
-    int64_t si = i + base, sj = j + base;
-    if (si >= N) si = N > 0 ? N - 1 : 0;
-    if (sj >= N) sj = N > 0 ? N - 1 : 0;
-    recv[e] = static_cast<int32_t>(si);
-    send[e] = static_cast<int32_t>(sj);
-    // receiver of the previous edge: only the same graph can break the order (an earlier graph's ids are smaller
-    // because node offsets grow with the graph index)
-    if (g_start < e && idx[(e - 1) * 2] + base > si) local_flags |= MP_FLAG_UNSORTED_COL0;
-    if (dist) {
-      const float dx = xyz[si * 3 + 0] - xyz[sj * 3 + 0];
-      const float dy = xyz[si * 3 + 1] - xyz[sj * 3 + 1];
-      const float dz = xyz[si * 3 + 2] - xyz[sj * 3 + 2];
-      dist[e] = sqrtf(fmaxf(dx * dx + dy * dy + dz * dz, 0.0f));
-    }
-  }
-  if (local_flags) atomicOr(flags, local_flags);
+__global__ __launch_bounds__(256) void edge_prepare_kernel(mp_prep::EdgePrepArgs p) {
+  mp_prep::edge_prepare_body<LDS_SPLITS>(p, blockIdx.x, gridDim.x);
 }
 
 __global__ void iota_kernel(int32_t* __restrict__ out, int64_t n) {
@@ -214,12 +142,11 @@ int mp_edge_prepare_i64_f32(const int64_t* idx, int64_t M, const int64_t* node_s
   MP_REQUIRE((dist == nullptr) || (xyz != nullptr), "mp_edge_prepare_i64_f32: dist requested without coordinates");
   if (M == 0) return MP_OK;
   MP_REQUIRE(idx && recv && send && node_splits && edge_splits && G > 0, "mp_edge_prepare_i64_f32: null pointer");
-  if (G <= PREP_LDS_GRAPHS) {
-    edge_prepare_kernel<true><<<mp::grid_for(M), 256, 0, mp::as_stream(stream)>>>(idx, M, node_splits, edge_splits, G, N,
-                                                                                   xyz, recv, send, dist, flags);
+  mp_prep::EdgePrepArgs p{idx, M, node_splits, edge_splits, G, N, xyz, recv, send, dist, flags};
+  if (G <= mp_prep::PREP_LDS_GRAPHS) {
+    edge_prepare_kernel<true><<<mp::grid_for(M), 256, 0, mp::as_stream(stream)>>>(p);
   } else {
-    edge_prepare_kernel<false><<<mp::grid_for(M), 256, 0, mp::as_stream(stream)>>>(idx, M, node_splits, edge_splits, G,
-                                                                                    N, xyz, recv, send, dist, flags);
+    edge_prepare_kernel<false><<<mp::grid_for(M), 256, 0, mp::as_stream(stream)>>>(p);
   }
   return mp::check_launch("mp_edge_prepare_i64_f32");
 }

@@ -14,6 +14,7 @@
 // the next.  The MID / LAST kernels also re-zero the aggregation rows they consumed, so the next cfconv launch
 // needs no memset.
 #include "mp_common.h"
+#include "mp_edge_prepare.h"
 
 namespace {
 
@@ -103,8 +104,10 @@ enum NodeMode { NODE_IN = 0, NODE_MID = 1, NODE_LAST = 2 };
     }                                                                 \
   }
 
+// `block` / `nblocks`: this workgroup's position among the workgroups running the node chain (the stage-0 kernel runs
+// edge preparation on the remaining workgroups of the same launch).
 template <int MODE, int E, int RB, bool FAST>
-__global__ __launch_bounds__(256, (RB == 4 && MODE != NODE_LAST) ? 2 : 1) void schnet_node_kernel(NodeArgs a) {
+__device__ __forceinline__ void schnet_node_body(const NodeArgs& a, int block, int nblocks) {
   __shared__ float Xa[16 * RB * X_LD];
   __shared__ float Xb[16 * RB * X_LD];
   const int tid = threadIdx.x;
@@ -167,7 +170,7 @@ __global__ __launch_bounds__(256, (RB == 4 && MODE != NODE_LAST) ? 2 : 1) void s
       }
     }
   };
-  if constexpr (EARLY_STAGE) stage_load(blockIdx.x);
+  if constexpr (EARLY_STAGE) stage_load(block);
 
   // ---- weight slices -> registers (once per persistent workgroup) -------------------------------------------
   float w_first[2][(MODE == NODE_IN ? E : F) / 4];   // IN: W0 ; MID/LAST: W2
@@ -202,7 +205,7 @@ __global__ __launch_bounds__(256, (RB == 4 && MODE != NODE_LAST) ? 2 : 1) void s
   }
   bias_fourth = (MODE == NODE_LAST && a.bl1) ? a.bl1[wave * 16 + (lane & 15)] : 0.0f;
 
-  for (int tile = blockIdx.x; tile < a.ntiles; tile += gridDim.x) {
+  for (int tile = block; tile < a.ntiles; tile += nblocks) {
     const int64_t node0 = static_cast<int64_t>(tile) * TN;
 
     // ---- stage the input tile into Xa (coalesced; the consumed aggregation rows were re-zeroed by stage_load) --------
@@ -214,7 +217,7 @@ __global__ __launch_bounds__(256, (RB == 4 && MODE != NODE_LAST) ? 2 : 1) void s
     }
     __syncthreads();
 
-    if constexpr (EARLY_STAGE) stage_load(tile + static_cast<int>(gridDim.x));  // next tile, in flight during the GEMMs
+    if constexpr (EARLY_STAGE) stage_load(tile + nblocks);  // next tile, in flight during the GEMMs
     floatx4 acc[RB][2];
     // residual rows of n, requested now so that the round trip hides under GEMM 1 and 2
     constexpr bool PREFETCH_N = RB == 1;  // the 64-node build spends its registers on two workgroups per CU instead
@@ -286,6 +289,24 @@ __global__ __launch_bounds__(256, (RB == 4 && MODE != NODE_LAST) ? 2 : 1) void s
       }
     }
     __syncthreads();  // Xa / Xb are reused by the next tile
+  }
+}
+
+template <int MODE, int E, int RB, bool FAST>
+__global__ __launch_bounds__(256, (RB == 4 && MODE != NODE_LAST) ? 2 : 1) void schnet_node_kernel(NodeArgs a) {
+  schnet_node_body<MODE, E, RB, FAST>(a, blockIdx.x, gridDim.x);
+}
+
+// Stage 0 of the fused forward: the node-input chain (Embedding -> Dense -> Dense_nobias) and the edge preparation
+// (index shift, receiver/sender split, flags, distance) are independent, and at QM9 batch sizes each alone fills less
+// than half of the chip for ~5 us - so one launch runs both, on disjoint workgroups (role by block index).
+template <int E, bool FAST, bool LDS_SPLITS>
+__global__ __launch_bounds__(256) void schnet_stage0_kernel(NodeArgs a, mp_prep::EdgePrepArgs p, int node_blocks) {
+  if (static_cast<int>(blockIdx.x) < node_blocks) {
+    schnet_node_body<NODE_IN, E, 1, FAST>(a, blockIdx.x, node_blocks);
+  } else {
+    mp_prep::edge_prepare_body<LDS_SPLITS>(p, static_cast<int64_t>(blockIdx.x) - node_blocks,
+                                           static_cast<int64_t>(gridDim.x) - node_blocks);
   }
 }
 
@@ -368,6 +389,38 @@ int mp_schnet_node_in_f32(const float* numbers, int64_t N, const float* emb, int
   a.N = N;
   a.numbers = numbers; a.emb = emb; a.vocab = vocab; a.W0 = W0; a.b0 = b0; a.Wx = Wx; a.n = n_out; a.x = x_out;
   return launch_node<NODE_IN, 64>(a, flags, mp::as_stream(stream), "mp_schnet_node_in_f32");
+}
+
+int mp_schnet_stage0_f32(const float* numbers, int64_t N, const float* emb, int vocab, int emb_dim, const float* W0,
+                         const float* b0, const float* Wx, float* n_out, float* x_out, const int64_t* idx, int64_t M,
+                         const int64_t* node_splits, const int64_t* edge_splits, int64_t G, const float* xyz,
+                         int32_t* recv, int32_t* send, float* dist, int32_t* flags, int flags_arg, mpStream_t stream) {
+  MP_REQUIRE(N >= 0 && M >= 0 && G >= 0 && vocab >= 1, "mp_schnet_stage0_f32: bad sizes");
+  MP_REQUIRE(emb_dim == 64, "mp_schnet_stage0_f32: built for embedding width 64 (got %d)", emb_dim);
+  MP_REQUIRE(N < (int64_t{1} << 31) && M < (int64_t{1} << 31), "mp_schnet_stage0_f32: N, M must fit int32");
+  const int64_t tiles16 = (N + 15) / 16;
+  if (N == 0 || M == 0 || tiles16 > 1024 || G > mp_prep::PREP_LDS_GRAPHS) {
+    // outside the latency-bound regime the two stages run as their own (throughput-shaped) launches
+    int rc = mp_edge_prepare_i64_f32(idx, M, node_splits, edge_splits, G, N, xyz, recv, send, dist, flags, stream);
+    if (rc != MP_OK) return rc;
+    return mp_schnet_node_in_f32(numbers, N, emb, vocab, emb_dim, W0, b0, Wx, n_out, x_out, flags_arg, stream);
+  }
+  MP_REQUIRE(numbers && emb && W0 && Wx && n_out && x_out && idx && node_splits && edge_splits && recv && send && flags,
+             "mp_schnet_stage0_f32: null pointer");
+  MP_REQUIRE((dist == nullptr) || (xyz != nullptr), "mp_schnet_stage0_f32: dist requested without coordinates");
+  NodeArgs a{};
+  a.N = N; a.ntiles = static_cast<int>(tiles16);
+  a.numbers = numbers; a.emb = emb; a.vocab = vocab; a.W0 = W0; a.b0 = b0; a.Wx = Wx; a.n = n_out; a.x = x_out;
+  mp_prep::EdgePrepArgs p{idx, M, node_splits, edge_splits, G, N, xyz, recv, send, dist, flags};
+  const int node_blocks = a.ntiles;
+  const int edge_blocks = static_cast<int>(mp::grid_for(M));
+  hipStream_t s = mp::as_stream(stream);
+  if (flags_arg & 1) {
+    schnet_stage0_kernel<64, true, true><<<node_blocks + edge_blocks, 256, 0, s>>>(a, p, node_blocks);
+  } else {
+    schnet_stage0_kernel<64, false, true><<<node_blocks + edge_blocks, 256, 0, s>>>(a, p, node_blocks);
+  }
+  return mp::check_launch("mp_schnet_stage0_f32");
 }
 
 int mp_schnet_node_update_f32(float* agg, int64_t N, const float* W2, const float* b2, const float* W3,

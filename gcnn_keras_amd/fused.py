@@ -1,7 +1,7 @@
-"""Fused SchNet forward: the arithmetic of kgcnn/literature/Schnet.py:104-148 in nine kernels, replayed from a HIP graph.
+"""Fused SchNet forward: the arithmetic of kgcnn/literature/Schnet.py:104-148 in eight kernels, replayed from a HIP graph.
 
-    edge_prepare        index shift + receiver/sender split + sortedness/range flags + edge distance   (1 launch)
-    node_in             Embedding -> Dense(64->128) -> Dense_nobias (block 0)                           (1 launch)
+    stage0              edge_prepare (index shift, receiver/sender split, flags, distance) and node_in
+                        (Embedding -> Dense(64->128) -> Dense_nobias) on disjoint workgroups             (1 launch)
     per block:          cfconv_gauss_fused (Gauss basis, filter MLP, gather, multiply, segment-sum)     (depth launches)
                         node_update / node_last (2-3 chained Dense on the node tile, residual)         (depth launches)
     readout             PoolingNodes(sum) + output MLP                                                 (1 launch)
@@ -54,7 +54,7 @@ class FusedSchnet:
         torch.cuda.synchronize()
         self.stream = torch.cuda.Stream()
         self.graph = None
-        self.num_launches = 2 + 2 * depth + 1
+        self.num_launches = 1 + 2 * depth + 1
         self._b = None
 
     # ------------------------------------------------------------------------------------------------ binding
@@ -113,14 +113,22 @@ class FusedSchnet:
         # One linear chain on one stream.  (A two-branch graph - node_in beside edge_prepare - was measured 9 % SLOWER
         # at config 2: the fork/join costs more than the ~5 us of overlap it buys.)
         p, b = self.p, self._b
-        self._prepare()
-        if not self.sorted and self.M > 0:
+        if self.sorted or self.M == 0:
+            # stage 0: node-input chain and edge preparation in one launch (independent work on disjoint workgroups)
+            _ffi.call("mp_schnet_stage0_f32", _ffi.ptr(b["z"]), self.N, _ffi.ptr(p["embedding"]),
+                      int(p["embedding"].shape[0]), 64, _ffi.ptr(p["dense0/kernel"]), _ffi.ptr(p.get("dense0/bias")),
+                      _ffi.ptr(p["interaction0/dense1/kernel"]), _ffi.ptr(self.n), _ffi.ptr(self.x),
+                      _ffi.ptr(b["idx"]), self.M, _ffi.ptr(b["ns"]), _ffi.ptr(b["es"]), self.G, _ffi.ptr(b["xyz"]),
+                      _ffi.ptr(self.recv), _ffi.ptr(self.send), _ffi.ptr(self.dist), _ffi.ptr(self.flags),
+                      self.flags_arg & 1, _ffi.stream())
+        else:
+            self._prepare()
             _ffi.call("mp_sort_segments_i32", _ffi.ptr(self.recv), self.M, _ffi.ptr(self.recv_sorted),
                       _ffi.ptr(self.perm), _ffi.ptr(self.sort_ws), self.sort_ws_bytes, _ffi.stream())
-        _ffi.call("mp_schnet_node_in_f32", _ffi.ptr(b["z"]), self.N, _ffi.ptr(p["embedding"]),
-                  int(p["embedding"].shape[0]), 64, _ffi.ptr(p["dense0/kernel"]), _ffi.ptr(p.get("dense0/bias")),
-                  _ffi.ptr(p["interaction0/dense1/kernel"]), _ffi.ptr(self.n), _ffi.ptr(self.x), self.flags_arg & 1,
-                  _ffi.stream())
+            _ffi.call("mp_schnet_node_in_f32", _ffi.ptr(b["z"]), self.N, _ffi.ptr(p["embedding"]),
+                      int(p["embedding"].shape[0]), 64, _ffi.ptr(p["dense0/kernel"]), _ffi.ptr(p.get("dense0/bias")),
+                      _ffi.ptr(p["interaction0/dense1/kernel"]), _ffi.ptr(self.n), _ffi.ptr(self.x),
+                      self.flags_arg & 1, _ffi.stream())
         for i in range(self.depth):
             pre = "interaction%d/" % i
             self._cfconv(i, self.agg)

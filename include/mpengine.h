@@ -235,6 +235,12 @@ int mp_painn_message_fused_f32(const float* s, const float* v, int64_t N, const 
  * flags bit0: fast softplus as in mp_cfconv_fused_f32. */
 int mp_schnet_node_in_f32(const float* numbers, int64_t N, const float* emb, int vocab, int emb_dim, const float* W0,
                           const float* b0, const float* Wx, float* n_out, float* x_out, int flags, mpStream_t stream);
+/* mp_schnet_node_in_f32 and mp_edge_prepare_i64_f32 in ONE launch (disjoint workgroups): they are independent and at
+ * QM9 batch sizes each alone occupies less than half of the chip; falls back to the two launches for large batches. */
+int mp_schnet_stage0_f32(const float* numbers, int64_t N, const float* emb, int vocab, int emb_dim, const float* W0,
+                         const float* b0, const float* Wx, float* n_out, float* x_out, const int64_t* idx, int64_t M,
+                         const int64_t* node_splits, const int64_t* edge_splits, int64_t G, const float* xyz,
+                         int32_t* recv, int32_t* send, float* dist, int32_t* flags, int flags_arg, mpStream_t stream);
 int mp_schnet_node_update_f32(float* agg, int64_t N, const float* W2, const float* b2, const float* W3,
                               const float* b3, float* n_inout, const float* Wx_next, float* x_out, int flags,
                               mpStream_t stream);
