@@ -77,6 +77,9 @@ _SIGNATURES = {
     "mp_schnet_node_update_f32": [P, c_int64, P, P, P, P, P, P, P, c_int, P],
     "mp_schnet_node_last_f32": [P, c_int64, P, P, P, P, P, P, P, P, P, P, c_int, P],
     "mp_schnet_readout_f32": [P, P, c_int64, P, P, P, P, P, P],
+    "mp_radius_graph_workspace_bytes": [c_int64, P],
+    "mp_radius_graph_count_f32": [P, P, c_int64, c_int64, c_float, c_int, P, P, P, c_size_t, P],
+    "mp_radius_graph_fill_f32": [P, P, c_int64, c_int64, c_float, c_int, P, c_int64, P, P, P, P, P],
     "mp_activation_grad_f32": [c_int, c_float, P, P, c_int64, P, P],
     "mp_sum_axis_f32": [P, c_int64, c_int64, c_int64, c_int, P, P],
     "mp_euclidean_norm_grad_f32": [P, P, c_int64, c_int64, c_int64, c_int, P, P],

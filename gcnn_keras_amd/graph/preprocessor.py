@@ -1,0 +1,63 @@
+"""On-GPU ``SetRange`` (mirror of kgcnn/graph/preprocessor.py:255-314 for a ragged batch resident in HBM).
+
+The reference runs ``define_adjacency_from_distance`` (kgcnn/graph/adj.py:537-593) per molecule in NumPy on the host
+and re-uploads the edge lists; here the whole batch goes through two kernels around one prefix sum
+(csrc/mp_radius.hip).  Same rule: ``dist < max_distance`` AND among the ``max_neighbours + 1`` nearest entries of the
+row (exclusive mode), no self loops, row-major ``(i, j)`` order - hence receiver-sorted output.
+"""
+import ctypes
+
+import torch
+
+from .. import _ffi
+from ..ragged import RaggedTensor
+
+
+class SetRange:
+
+    def __init__(self, *, range_indices: str = "range_indices", node_coordinates: str = "node_coordinates",
+                 range_attributes: str = "range_attributes", max_distance: float = 4.0, max_neighbours: int = 15,
+                 do_invert_distance: bool = False, self_loops: bool = False, exclusive: bool = True, name="set_range",
+                 overwrite: bool = True, **kwargs):
+        if self_loops or not exclusive or do_invert_distance:
+            raise NotImplementedError("on-GPU SetRange covers the configuration the training scripts use: exclusive, "
+                                      "no self loops, plain distances")
+        self.name = name
+        self._config_kwargs = {"node_coordinates": node_coordinates, "range_indices": range_indices,
+                               "range_attributes": range_attributes, "max_distance": max_distance,
+                               "max_neighbours": max_neighbours, "do_invert_distance": do_invert_distance,
+                               "self_loops": self_loops, "exclusive": exclusive, "overwrite": overwrite}
+        self.max_distance = max_distance
+        self.max_neighbours = max_neighbours
+
+    def get_config(self):
+        return {"name": self.name, **self._config_kwargs}
+
+    def __call__(self, node_coordinates: RaggedTensor):
+        """``node_coordinates``: ragged ``(batch, [N], 3)`` float32.  Returns ``(range_indices, range_attributes)``:
+        ragged ``(batch, [M], 2)`` int64 sample indices and ragged ``(batch, [M], 1)`` distances; the returned index
+        tensor carries a ready index plan (int32 ids + receiver CSR), so the first gather / pooling costs nothing."""
+        xyz = node_coordinates.values.contiguous()
+        _ffi.require_device(xyz, node_coordinates.row_splits)
+        n, g = int(xyz.shape[0]), node_coordinates.nrows()
+        dev = xyz.device
+        md = -1.0 if self.max_distance is None else float(self.max_distance)
+        mn = -1 if self.max_neighbours is None else int(min(self.max_neighbours, 2 ** 30))
+        nbytes = ctypes.c_size_t(0)
+        _ffi.call("mp_radius_graph_workspace_bytes", n, ctypes.byref(nbytes))
+        ws = torch.empty(max(nbytes.value, 1), dtype=torch.uint8, device=dev)
+        node_ptr = torch.empty(n + 1, dtype=torch.int32, device=dev)
+        edge_splits = torch.empty(g + 1, dtype=torch.int64, device=dev)
+        _ffi.call("mp_radius_graph_count_f32", _ffi.ptr(xyz), _ffi.ptr(node_coordinates.row_splits), g, n, md, mn,
+                  _ffi.ptr(node_ptr), _ffi.ptr(edge_splits), _ffi.ptr(ws), nbytes.value, _ffi.stream())
+        m = int(node_ptr[-1].item())  # the output size is data dependent: one host read, as in the reference pipeline
+        idx = torch.empty((m, 2), dtype=torch.int64, device=dev)
+        cols = torch.empty((2, max(m, 1)), dtype=torch.int32, device=dev)
+        recv, send = cols[0], cols[1]
+        dist = torch.empty((m, 1), dtype=torch.float32, device=dev)
+        _ffi.call("mp_radius_graph_fill_f32", _ffi.ptr(xyz), _ffi.ptr(node_coordinates.row_splits), g, n, md, mn,
+                  _ffi.ptr(node_ptr), m, _ffi.ptr(idx), _ffi.ptr(recv), _ffi.ptr(send), _ffi.ptr(dist), _ffi.stream())
+        indices = RaggedTensor(idx, edge_splits)
+        from ..ragged import IndexPlan
+        indices.attach_plan(node_coordinates, IndexPlan.from_prepared(indices, node_coordinates, cols, node_ptr))
+        return indices, RaggedTensor(dist, edge_splits)

@@ -116,6 +116,9 @@ class RaggedTensor:
         return "<RaggedTensor shape=%s dtype=%s device=%s>" % (self.shape, self.dtype, self.device)
 
     # ---- index plan -------------------------------------------------------------------------------------------
+    def attach_plan(self, nodes, plan):
+        self._plans[(nodes.row_splits.data_ptr(), int(nodes.values.shape[0]))] = plan
+
     def index_plan(self, nodes):
         """Plan of this (batch, [M], K) index tensor against the node partition of ``nodes``."""
         key = (nodes.row_splits.data_ptr(), int(nodes.values.shape[0]))
@@ -154,6 +157,21 @@ class IndexPlan:
                   _ffi.ptr(idx.row_splits), self.G, self.N, _ffi.ptr(self.cols), _ffi.ptr(self.flags), _ffi.stream())
         self._flags_host = None
         self._csr = {}
+
+    @classmethod
+    def from_prepared(cls, idx, nodes, cols, csr_ptr=None):
+        """Plan for indices whose shifted int32 columns (and receiver CSR) a producer kernel already wrote
+        (on-GPU ``SetRange``): range-checked and receiver-sorted by construction, nothing to launch."""
+        self = cls.__new__(cls)
+        self.M, self.K = int(idx.values.shape[0]), int(idx.values.shape[1])
+        self.N, self.G = int(nodes.values.shape[0]), idx.nrows()
+        self.cols = cols
+        self.flags = torch.zeros(1, dtype=torch.int32, device=cols.device)
+        self._flags_host = _ffi.MP_FLAG_UNSORTED_COL1  # column 0 sorted; column 1 not claimed
+        self._csr = {}
+        if csr_ptr is not None:
+            self._csr[(0, False)] = self._csr[(0, True)] = (csr_ptr, None, cols[0, :self.M])
+        return self
 
     def flags_host(self):
         if self._flags_host is None:

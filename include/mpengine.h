@@ -250,6 +250,21 @@ int mp_schnet_node_last_f32(float* agg, int64_t N, const float* W2, const float*
 int mp_schnet_readout_f32(const float* h, const int64_t* node_splits, int64_t G, const float* Wo0, const float* bo0,
                           const float* Wo1, const float* bo1, float* out, mpStream_t stream);
 
+/* ---------------------------------------------------------------- on-GPU SetRange (next: SURVEY 8f.2) ---- */
+/* SetRange.call, kgcnn/graph/preprocessor.py:288-314 via define_adjacency_from_distance (kgcnn/graph/adj.py:537-593),
+ * exclusive mode, no self loops, for a whole ragged batch of coordinates xyz (N,3): pass 1 counts the edges of every
+ * receiving atom and scans them (node_ptr (N+1) int32 = receiver CSR, edge_splits (G+1) int64); the caller reads
+ * M = node_ptr[N] to size the outputs; pass 2 writes the (M,2) int64 sample indices in row-major (i,j) order and,
+ * optionally, int32 receiver / sender ids and the edge distances (range_attributes).  max_distance < 0 or
+ * max_neighbours < 0 disables that criterion. */
+int mp_radius_graph_workspace_bytes(int64_t N, size_t* bytes_out_host);
+int mp_radius_graph_count_f32(const float* xyz, const int64_t* node_splits, int64_t G, int64_t N, float max_distance,
+                              int max_neighbours, int32_t* node_ptr, int64_t* edge_splits, void* ws, size_t ws_bytes,
+                              mpStream_t stream);
+int mp_radius_graph_fill_f32(const float* xyz, const int64_t* node_splits, int64_t G, int64_t N, float max_distance,
+                             int max_neighbours, const int32_t* node_ptr, int64_t M, int64_t* idx_out, int32_t* recv,
+                             int32_t* send, float* dist, mpStream_t stream);
+
 /* ---------------------------------------------------------------- backward helpers (forces) -------------- */
 /* EnergyForceModel, kgcnn/model/force.py:159-186: F = -dE/dx needs one reverse pass.  Gather-backward is
  * mp_segment_reduce_csr_f32 over the CSR of the gathered column, segment-sum-backward is mp_gather_rows_f32 by the
