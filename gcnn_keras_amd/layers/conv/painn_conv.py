@@ -20,6 +20,17 @@ def _kernel_args(kernel_regularizer, bias_regularizer, activity_regularizer, ker
             "bias_initializer": bias_initializer}
 
 
+_DENSE_CONFIG_KEYS = ("kernel_regularizer", "activity_regularizer", "bias_regularizer", "kernel_constraint",
+                      "bias_constraint", "kernel_initializer", "bias_initializer", "activation", "use_bias")
+
+
+def _with_dense_config(config, dense_layer):
+    """Copy the sub-Dense entries the reference exposes on the block itself (painn_conv.py:117-125, :216-224)."""
+    dense_conf = dense_layer.get_config()
+    config.update({key: dense_conf[key] for key in _DENSE_CONFIG_KEYS})
+    return config
+
+
 class SplitEmbedding(GraphBaseLayer):
     """Split the last axis of a ragged tensor into equal parts (kgcnn/layers/conv/painn_conv.py:301-346)."""
 
@@ -139,11 +150,7 @@ class PAiNNconv(GraphBaseLayer):
     def get_config(self):
         config = super().get_config()
         config.update({"conv_pool": self.conv_pool, "units": self.units, "cutoff": self.cutoff})
-        config_dense = self.lay_dense1.get_config()
-        for x in ["kernel_regularizer", "activity_regularizer", "bias_regularizer", "kernel_constraint",
-                  "bias_constraint", "kernel_initializer", "bias_initializer", "activation", "use_bias"]:
-            config.update({x: config_dense[x]})
-        return config
+        return _with_dense_config(config, self.lay_dense1)
 
 
 class PAiNNUpdate(GraphBaseLayer):
@@ -198,11 +205,7 @@ class PAiNNUpdate(GraphBaseLayer):
     def get_config(self):
         config = super().get_config()
         config.update({"units": self.units})
-        config_dense = self.lay_dense1.get_config()
-        for x in ["kernel_regularizer", "activity_regularizer", "bias_regularizer", "kernel_constraint",
-                  "bias_constraint", "kernel_initializer", "bias_initializer", "activation", "use_bias"]:
-            config.update({x: config_dense[x]})
-        return config
+        return _with_dense_config(config, self.lay_dense1)
 
 
 class EquivariantInitialize(GraphBaseLayer):
