@@ -38,7 +38,6 @@ using floatx16 = __attribute__((ext_vector_type(16))) float;
 
 constexpr int F = 128;          // feature width of the fused kernel
 constexpr int TE = 32;          // edges per wave tile
-constexpr int T_LD = 36;        // padded edge stride of the per-wave transpose slab (floats)
 constexpr int MAX_KROWS = 34;   // W1 rows in LDS: B inputs + 1 bias row, padded to even (B <= 32)
 
 __device__ __forceinline__ int rowmap(int r, int hh) { return (r & 3) + 8 * (r >> 2) + 4 * hh; }
@@ -86,7 +85,6 @@ __global__ __launch_bounds__(WAVES * 64) void cfconv_fused_kernel(CfconvArgs a) 
   extern __shared__ __align__(16) float lds[];
   float* W1s = lds;                          // [MAX_KROWS][F] packed
   float* W2s = lds + MAX_KROWS * F;          // [F][F] packed
-  float* Ts = W2s + F * F;                   // [WAVES][F][T_LD]
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -105,13 +103,20 @@ __global__ __launch_bounds__(WAVES * 64) void cfconv_fused_kernel(CfconvArgs a) 
   int nx_send = 0, nx_recv = 0;
   float nx_d = 0.0f;
   int64_t nx_ep = 0;
+  // Lane c does not take edge c of the tile but edge eps(c): with that assignment the accumulator rows of GEMM2
+  // (row = (r&3) + 8(r>>2) + 4hh) hold, per lane half, SIXTEEN CONSECUTIVE edges in register order (edge 16hh + r), so
+  // the segmented sum below runs in registers.  Receiver ids are additionally kept in plain edge order (lane c <-> edge c)
+  // for the segment mask.
+  const int eps_c = 16 * ((c >> 2) & 1) + (c & 3) + 4 * (c >> 3);
   auto prefetch_tile = [&](int t) {
     if (t < a.ntiles) {
-      const int64_t e = static_cast<int64_t>(t) * TE + c;
+      const int64_t e0n = static_cast<int64_t>(t) * TE;
+      const int64_t e = e0n + eps_c;
       const int64_t ec = e < a.M ? e : a.M - 1;
       nx_ep = a.perm ? static_cast<int64_t>(a.perm[ec]) : ec;
       nx_send = a.send[nx_ep];
-      nx_recv = a.recv[ec];
+      const int64_t es = (e0n + c) < a.M ? (e0n + c) : a.M - 1;
+      nx_recv = a.recv[es];
       if constexpr (GAUSS) nx_d = a.edge_in[nx_ep];
     }
   };
@@ -144,14 +149,13 @@ __global__ __launch_bounds__(WAVES * 64) void cfconv_fused_kernel(CfconvArgs a) 
   bool w2_ready = false;  // wave-uniform: every wave passes the publishing barrier exactly once
 
   MP_STAMP(0)
-  float* T = Ts + wave * ((WAVES > 4 ? F / 2 : F) * T_LD);
   const float* w1_lane = W1s + (nk * hh) * F + 4 * c;  // + s*F           : rows s (lo half) / nk+s (hi half)
   const float* w2_lane = W2s + (4 * hh) * F + 4 * c;   // + (ib*32 + (r&3) + 8*(r>>2))*F
 
   for (int tile0 = tile_first; tile0 < a.ntiles; tile0 += tile_step) {
     const int tile = __builtin_amdgcn_readfirstlane(tile0);
     const int64_t e0 = static_cast<int64_t>(tile) * TE;
-    const int64_t e_mine = e0 + c;
+    const int64_t e_mine = e0 + eps_c;
     const bool valid = e_mine < a.M;
     const int64_t ep = nx_ep;
     const int my_send = nx_send;
@@ -162,9 +166,9 @@ __global__ __launch_bounds__(WAVES * 64) void cfconv_fused_kernel(CfconvArgs a) 
     float xv[4][16];
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
-      const int row = rowmap(r, hh);
+      const int row = rowmap(r, hh);               // MFMA row; its lane handles edge 16 hh + r
       const int snode = __shfl(my_send, row, 64);
-      const bool row_valid = (e0 + row) < a.M;
+      const bool row_valid = (e0 + 16 * hh + r) < a.M;
       const float* xrow = a.x + static_cast<int64_t>(snode) * F + c;
 #pragma unroll
       for (int jb = 0; jb < 4; ++jb) {
@@ -252,69 +256,93 @@ __global__ __launch_bounds__(WAVES * 64) void cfconv_fused_kernel(CfconvArgs a) 
     }
 
     MP_STAMP(4)
-    // ---- multiply by the sender row, transpose through the slab [feature][edge] and sum the segments in edge order.
-    //      Segment starts come from one ballot (a scalar bit mask), receiver ids from v_readlane: no memory access and
-    //      only scalar branches inside the walk.  Padding edges of the last tile repeat the last receiver and carry
-    //      zeros.  With 8 waves per workgroup the slab holds 64 features and the epilogue runs in two passes. --------
+    // ---- multiply by the sender row and sum the segments IN REGISTERS.  Each lane half holds 16 consecutive edges of
+    //      one feature column per block; it walks them with lane-varying predicates (v_cndmask, no LDS, no scalar
+    //      branches per edge): a segment that closes inside the half is stored at once (it is interior to the tile)
+    //      except the half's first one, which is kept; afterwards the low half's open tail is handed to the high half
+    //      if the segment continues across edge 15|16, and the (at most four) boundary segments are written: plain
+    //      stores for tile-interior ones, one float atomic for the tile's first and last segment, which may continue in
+    //      the neighbouring tiles.  Padding edges of the last tile repeat the last receiver and carry zeros. -----------
     const int prev_recv = __shfl_up(my_recv, 1, 64);  // all lanes take part; lanes 0 / 32 are masked out below
     const unsigned start_mask =
         static_cast<unsigned>(__ballot((c > 0) & (my_recv != prev_recv)) & 0xffffffffull);
-    constexpr int NPASS = (WAVES > 4) ? 2 : 1;   // passes over the feature dimension
-    constexpr int JBP = 4 / NPASS;               // 32-wide feature blocks per pass
-    constexpr int NCOL = JBP / 2;                // features per lane per pass
+    const unsigned half_mask = hh ? (start_mask >> 16) : (start_mask & 0xffffu);  // bit r: edge 16hh + r opens a segment
+    int my_rows[16];  // receiver of each of this half's edges
 #pragma unroll
-    for (int pass = 0; pass < NPASS; ++pass) {
+    for (int r = 0; r < 16; ++r) my_rows[r] = __shfl(my_recv, 16 * hh + r, 64);
+    float acc[4], first[4];
+    int closed = 0;  // segments closed so far in this half
 #pragma unroll
-      for (int q = 0; q < 4; ++q) {
+    for (int jb = 0; jb < 4; ++jb) {
+      acc[jb] = w[jb][0] * xv[jb][0];
+      first[jb] = 0.0f;
+    }
+    float* const out_col = a.out + c;
 #pragma unroll
-        for (int jl = 0; jl < JBP; ++jl) {
-          const int jb = pass * JBP + jl;
-          const float4 m = make_float4(w[jb][4 * q] * xv[jb][4 * q], w[jb][4 * q + 1] * xv[jb][4 * q + 1],
-                                       w[jb][4 * q + 2] * xv[jb][4 * q + 2], w[jb][4 * q + 3] * xv[jb][4 * q + 3]);
-          *reinterpret_cast<float4*>(T + (jl * 32 + c) * T_LD + 8 * q + 4 * hh) = m;
-        }
+    for (int r = 1; r < 16; ++r) {
+      const bool opens = (half_mask >> r) & 1u;
+      if (opens && closed > 0) {  // a segment strictly inside the half: exclusive to this tile
+        float* dst = out_col + static_cast<int64_t>(my_rows[r - 1]) * F;
+#pragma unroll
+        for (int jb = 0; jb < 4; ++jb) dst[jb * 32] = acc[jb];
       }
-      if (pass == 0) { MP_STAMP(5) }
-      // the slab is private to this wave: LDS operations of one wave complete in order, no barrier needed
-      float v[NCOL][TE];
 #pragma unroll
-      for (int k = 0; k < NCOL; ++k)
+      for (int jb = 0; jb < 4; ++jb) {
+        const float m = w[jb][r] * xv[jb][r];
+        first[jb] = (opens && closed == 0) ? acc[jb] : first[jb];
+        acc[jb] = opens ? m : acc[jb] + m;
+      }
+      closed += opens ? 1 : 0;
+    }
+    MP_STAMP(5)
+    // wave-uniform shape of the tile
+    const int nlo = __builtin_popcount(start_mask & 0xfffeu) + 1;   // segments touching the low half
+    const int nhi = __builtin_popcount(start_mask >> 17) + 1;        // segments touching the high half
+    const bool cont = ((start_mask >> 16) & 1u) == 0;                // edge 16 continues the segment of edge 15
+    // hand the low half's open tail to the high half (lanes c+32) if the segment continues
+    float tail[4];
 #pragma unroll
-        for (int q = 0; q < 8; ++q) {
-          const float4 t4 = *reinterpret_cast<const float4*>(T + (64 * k + lane) * T_LD + 4 * q);
-          v[k][4 * q] = t4.x; v[k][4 * q + 1] = t4.y; v[k][4 * q + 2] = t4.z; v[k][4 * q + 3] = t4.w;
-        }
-      if (pass == 0) { MP_STAMP(6) }
-      float acc[NCOL];
+    for (int jb = 0; jb < 4; ++jb) tail[jb] = __shfl_xor(acc[jb], 32, 64);  // in hi lanes: the low half's tail
+    MP_STAMP(6)
+    if (hh == 0) {
+      if (nlo > 1) {  // the tile's first segment closed inside the low half
+        float* dst = out_col + static_cast<int64_t>(__builtin_amdgcn_readlane(my_recv, 0)) * F;
 #pragma unroll
-      for (int k = 0; k < NCOL; ++k) acc[k] = v[k][0];
-      bool first = true;
-      float* const out_lane = a.out + pass * (F / NPASS) + lane;
+        for (int jb = 0; jb < 4; ++jb) atomicAdd(dst + jb * 32, first[jb]);
+      }
+      if (!cont) {    // the low half's last segment ends at edge 15
+        float* dst = out_col + static_cast<int64_t>(__builtin_amdgcn_readlane(my_recv, 15)) * F;
+        if (nlo == 1) {
 #pragma unroll
-      for (int i = 1; i < TE; ++i) {
-        if ((start_mask >> i) & 1u) {
-          const int cur = __builtin_amdgcn_readlane(my_recv, i - 1);
-          float* dst = out_lane + static_cast<int64_t>(cur) * F;
-          if (first) {
-#pragma unroll
-            for (int k = 0; k < NCOL; ++k) atomicAdd(dst + 64 * k, acc[k]);
-            first = false;
-          } else {
-#pragma unroll
-            for (int k = 0; k < NCOL; ++k) dst[64 * k] = acc[k];
-          }
-#pragma unroll
-          for (int k = 0; k < NCOL; ++k) acc[k] = v[k][i];
+          for (int jb = 0; jb < 4; ++jb) atomicAdd(dst + jb * 32, acc[jb]);   // it is also the tile's first
         } else {
 #pragma unroll
-          for (int k = 0; k < NCOL; ++k) acc[k] += v[k][i];
+          for (int jb = 0; jb < 4; ++jb) dst[jb * 32] = acc[jb];
         }
       }
-      {
-        const int cur = __builtin_amdgcn_readlane(my_recv, TE - 1);
-        float* dst = out_lane + static_cast<int64_t>(cur) * F;
+    } else {
+      // the high half's first segment (the whole half if nhi == 1), plus the low half's tail when it continues
+      float v0[4];
 #pragma unroll
-        for (int k = 0; k < NCOL; ++k) atomicAdd(dst + 64 * k, acc[k]);
+      for (int jb = 0; jb < 4; ++jb) {
+        const float mine = nhi > 1 ? first[jb] : acc[jb];
+        v0[jb] = cont ? tail[jb] + mine : mine;   // edge order: low-half part first
+      }
+      {
+        float* dst = out_col + static_cast<int64_t>(__builtin_amdgcn_readlane(my_recv, 16)) * F;
+        const bool boundary = (cont && nlo == 1) || nhi == 1;   // contains the tile's first or last edge
+        if (boundary) {
+#pragma unroll
+          for (int jb = 0; jb < 4; ++jb) atomicAdd(dst + jb * 32, v0[jb]);
+        } else {
+#pragma unroll
+          for (int jb = 0; jb < 4; ++jb) dst[jb * 32] = v0[jb];
+        }
+      }
+      if (nhi > 1) {  // the tile's last segment
+        float* dst = out_col + static_cast<int64_t>(__builtin_amdgcn_readlane(my_recv, 31)) * F;
+#pragma unroll
+        for (int jb = 0; jb < 4; ++jb) atomicAdd(dst + jb * 32, acc[jb]);
       }
     }
     MP_STAMP(7)
@@ -355,7 +383,7 @@ __global__ void cfconv_pack_kernel(const float* __restrict__ W1, const float* __
 
 template <int WAVES>
 size_t cfconv_lds_bytes() {
-  return sizeof(float) * (MAX_KROWS * F + F * F + WAVES * (WAVES > 4 ? F / 2 : F) * T_LD);
+  return sizeof(float) * (MAX_KROWS * F + F * F);
 }
 
 template <int WAVES, bool GAUSS, bool FAST, int NKT, bool DIAG>

@@ -53,7 +53,7 @@ def diag(graphs):
     cyc = d.cpu().numpy().astype(np.float64).sum() / waves
     print("diag kernel %.1f us, %.0f shader cycles per wave -> clock %.2f GHz" % (ms * 1e3, cyc, cyc / (ms * 1e3) / 1e3))
     v = d.cpu().numpy().astype(np.float64)
-    names = ["stage", "setup+gauss", "gemm1", "ssp+xload", "gemm2", "mul+Twrite", "Tread", "walk+flush"]
+    names = ["stage", "setup+gauss", "gemm1", "ssp+xload", "gemm2", "seg-accumulate", "tail-xchg", "boundary-flush"]
     ntiles = (m + 31) // 32
     print("diag graphs=%d tiles=%d: " % (graphs, ntiles) + "  ".join("%s %.1f%%" % (nm, 100 * x / v.sum()) for nm, x in zip(names, v)))
     print("   cycles per tile: " + "  ".join("%s %.0f" % (nm, x / ntiles) for nm, x in zip(names[1:], v[1:])),
