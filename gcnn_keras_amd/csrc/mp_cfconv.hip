@@ -13,21 +13,31 @@
 // 1e-5 budget - there is no TF32 on gfx950.
 //
 // Structure (F = 128 fixed; wave64; one wave owns a tile of 32 consecutive edges of the receiver-sorted list):
-//  * W1 (+ its bias as an extra input row) and W2 live in LDS for the whole persistent workgroup, stored
-//    [k][4*c + blk] so that one ds_read_b128 yields the operands of all four 32-wide feature blocks.
+//  * W1 (+ its bias as an extra input row) and W2 live in LDS for the whole persistent workgroup.  W1 rows are stored
+//    [4*c + blk] so that one ds_read_b128 yields the A operands of all four 32-wide hidden blocks; W2 is stored
+//    naturally and lane c of GEMM2 owns the four output features 4c..4c+3 (one per accumulator block), again one
+//    ds_read_b128 per k step.
 //  * GEMM1 is computed TRANSPOSED, hT[f][e] = sum_b W1[b][f] rbf[e][b]: its accumulator then has the edge on the
 //    lane and the feature in the register, which is exactly the A-operand layout of GEMM2 (edge rows, k = feature)
 //    - the 128x32 hidden tile goes from one MFMA chain to the next in registers, no LDS round trip, no shuffles.
 //    The k order of GEMM2 is the accumulator's register order (a permutation of 0..127), the weights are read in
 //    that order.
-//  * GEMM2 w[e][j] leaves the output feature on the lane and the edge in the register: the sender gather
-//    x[send[e]][j] is a coalesced 128-B read per half wave, the multiply is in place.
-//  * Segment-sum: the 32x128 message tile is transposed through a private LDS slab ([feature][edge], padded),
-//    each lane then owns two features and walks the 32 edges in order with the (wave-uniform, scalar) receiver
-//    ids: interior segments are stored, the first and last segment of a tile - which may continue in the
-//    neighbouring tile - are added with one 256-B float atomic per 64 features.  A node whose edges span two
-//    tiles receives two adds onto a zero row, so the result is order independent (a + b == b + a); only
-//    receivers spanning three or more tiles (in-degree > 32) can differ in the last bit between runs.
+//  * Lane c of the wave does not take edge c of the tile but edge eps(c), a permutation chosen so that the accumulator
+//    of GEMM2 holds, per lane half, SIXTEEN CONSECUTIVE edges in register order.  The sender gather x[send[e]][4c..4c+3]
+//    is then one 16-B load per lane and edge (a half wave reads a whole 512-B row), the multiply is in place, and the
+//  * segment-sum is a register walk: the segment structure of a tile is one 32-bit start mask (a ballot over the
+//    sorted receiver ids), i.e. wave-uniform, so the walk is driven by scalar tests - a step without a boundary is
+//    two v_pk_mul_f32 + two v_pk_add_f32, a step with one branches (s_cbranch) into code that stores the closed
+//    segment (16 B per lane) under a lane mask built on the scalar unit.  Segments interior to the tile are stored;
+//    the first and last segment of a tile - which may continue in the neighbouring tile - are added with float
+//    atomics, after a 512-B lane transposition through LDS that makes each atomic instruction cover one contiguous
+//    128-B line (device-scope atomics are paid per line).  A node whose edges span two tiles receives two adds onto a
+//    zero row, so the result is order independent (a + b == b + a); only receivers spanning three or more tiles
+//    (in-degree > 32) can differ in the last bit between runs.
+//  * FP32 MFMA and FP32 VALU share the SIMD's FP32 lanes on gfx950 (scripts/probes/mfma_probe.hip: a VALU instruction
+//    between two MFMAs of the same wave adds its full issue time, only scalar / LDS / memory instructions overlap), so
+//    with one wave per SIMD the kernel's time is 64 cycles per MFMA PLUS ~5 cycles per vector instruction: the
+//    non-matrix phases are written for instruction count (packed FP32, scalar control, 6-instruction softplus).
 //  * The output buffer must be zero on entry (unconnected nodes keep 0 = the has_unconnected pad of
 //    kgcnn/layers/pooling.py:74-76).
 #include "mp_common.h"
@@ -35,6 +45,7 @@
 namespace {
 
 using floatx16 = __attribute__((ext_vector_type(16))) float;
+using floatx2 = __attribute__((ext_vector_type(2))) float;
 
 constexpr int F = 128;          // feature width of the fused kernel
 constexpr int TE = 32;          // edges per wave tile
@@ -45,10 +56,15 @@ __device__ __forceinline__ int rowmap(int r, int hh) { return (r & 3) + 8 * (r >
 // shifted softplus, kgcnn/ops/activ.py:15, in the form max(x,0) + log1p(exp(-|x|)) - log(2): identical to TF's
 // thresholded log1p(exp(x)) up to float rounding (|delta| < 2e-7 absolute) and free of overflow.
 __device__ __forceinline__ float ssp_fast(float x) {
-  // v_exp_f32 / v_log_f32 are base-2: t = 2^(-|x| log2 e), ssp = max(x,0) + ln2 * (log2(1 + t) - 1)
+  // v_exp_f32 / v_log_f32 are base-2: t = 2^(-|x| log2 e), ssp = max(x,0) + ln2 * log2((1 + t) / 2).  Six VALU
+  // instructions: the halving is exact and folded into one fma, max(x, 0) is an integer max on the bit pattern (no
+  // canonicalising v_max in front of it) - FP32 MFMA and VALU share the SIMD's FP32 lanes on gfx950, so every VALU
+  // instruction of this kernel is time taken from the matrix pipe (scripts/probes/mfma_probe.hip).
   const float t = __builtin_amdgcn_exp2f(fabsf(x) * -1.4426950408889634f);
-  const float l = __builtin_amdgcn_logf(1.0f + t);
-  return fmaf(l - 1.0f, 0.6931471805599453f, fmaxf(x, 0.0f));
+  const float l = __builtin_amdgcn_logf(__builtin_fmaf(t, 0.5f, 0.5f));
+  const int xi = __float_as_int(x);
+  const float relu = __int_as_float(xi > 0 ? xi : 0);
+  return __builtin_fmaf(l, 0.6931471805599453f, relu);
 }
 __device__ __forceinline__ float ssp_exact(float x) { return mp_softplus(x) - 0.6931471805599453f; }
 
@@ -84,7 +100,8 @@ __global__ __launch_bounds__(WAVES * 64) void cfconv_fused_kernel(CfconvArgs a) 
   if constexpr (DIAG) t_prev = __builtin_amdgcn_s_memtime();
   extern __shared__ __align__(16) float lds[];
   float* W1s = lds;                          // [MAX_KROWS][F] packed
-  float* W2s = lds + MAX_KROWS * F;          // [F][F] packed
+  float* W2s = lds + MAX_KROWS * F;          // [F][F] natural
+  float* Xs = W2s + F * F;                   // [WAVES][2][F] lane-transposition scratch for the boundary atomics
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -134,7 +151,7 @@ __global__ __launch_bounds__(WAVES * 64) void cfconv_fused_kernel(CfconvArgs a) 
   }
   float bias2[4];
 #pragma unroll
-  for (int jb = 0; jb < 4; ++jb) bias2[jb] = a.packed[MAX_KROWS * F + F * F + jb * 32 + c];
+  for (int jb = 0; jb < 4; ++jb) bias2[jb] = a.packed[MAX_KROWS * F + F * F + 4 * c + jb];
   __syncthreads();
   {
     constexpr int CHUNKS_PER_WAVE = (F * F / 256) / WAVES;  // 1-KB chunks of the W2 image per wave
@@ -162,19 +179,18 @@ __global__ __launch_bounds__(WAVES * 64) void cfconv_fused_kernel(CfconvArgs a) 
     const int my_recv = nx_recv;
     const float d_mine = nx_d;
 
-    // ---- sender rows of this tile: issued first, consumed after GEMM2 (coalesced 128-B reads per half wave) --------
+    // ---- sender rows of this tile: issued first, consumed after GEMM2 (one 16-B read per lane and edge: a half wave reads one whole 512-B row) --------
     float xv[4][16];
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const int row = rowmap(r, hh);               // MFMA row; its lane handles edge 16 hh + r
       const int snode = __shfl(my_send, row, 64);
-      const bool row_valid = (e0 + 16 * hh + r) < a.M;
-      const float* xrow = a.x + static_cast<int64_t>(snode) * F + c;
-#pragma unroll
-      for (int jb = 0; jb < 4; ++jb) {
-        const float t = xrow[jb * 32];  // always in range: padding rows reuse the last valid edge's sender
-        xv[jb][r] = row_valid ? t : 0.0f;
-      }
+      // always in range: padding rows reuse the last valid edge's sender
+      const float4 t = *reinterpret_cast<const float4*>(a.x + static_cast<int64_t>(snode) * F + 4 * c);
+      xv[0][r] = t.x;
+      xv[1][r] = t.y;
+      xv[2][r] = t.z;
+      xv[3][r] = t.w;
     }
     prefetch_tile(tile0 + tile_step);  // next tile's edge data, in flight during this tile's GEMMs
 
@@ -256,69 +272,93 @@ __global__ __launch_bounds__(WAVES * 64) void cfconv_fused_kernel(CfconvArgs a) 
     }
 
     MP_STAMP(4)
-    // ---- multiply by the sender row and sum the segments IN REGISTERS.  Each lane half holds 16 consecutive edges of
-    //      one feature column per block; it walks them with lane-varying predicates (v_cndmask, no LDS, no scalar
-    //      branches per edge): a segment that closes inside the half is stored at once (it is interior to the tile)
-    //      except the half's first one, which is kept; afterwards the low half's open tail is handed to the high half
-    //      if the segment continues across edge 15|16, and the (at most four) boundary segments are written: plain
-    //      stores for tile-interior ones, one float atomic for the tile's first and last segment, which may continue in
-    //      the neighbouring tiles.  Padding edges of the last tile repeat the last receiver and carry zeros. -----------
+    // ---- multiply by the sender row and sum the segments IN REGISTERS.  Each lane half holds 16 consecutive edges
+    //      (register order) of the lane's four feature columns.  The segment structure is wave-uniform data (one
+    //      32-bit start mask from a ballot), so the walk is driven by SCALAR tests: a step without a boundary in either
+    //      half is four multiply-adds; a step with one takes a scalar branch into the general code, where lane masks
+    //      built on the scalar unit select which half stores / restarts.  A segment that closes inside a half after
+    //      another one opened there is exclusive to this tile: one 16-B store per lane.  The (at most four) segments that
+    //      touch a half boundary are resolved afterwards: the low half's open tail moves to the high half if the
+    //      segment continues across edge 15|16; tile-interior ones are stored, the tile's first and last segment -
+    //      which may continue in the neighbouring tiles - are added with float atomics.  Padding edges of the last
+    //      tile repeat the last receiver and carry zeros. -----------------------------------------------------------------
     const int prev_recv = __shfl_up(my_recv, 1, 64);  // all lanes take part; lanes 0 / 32 are masked out below
-    const unsigned start_mask =
-        static_cast<unsigned>(__ballot((c > 0) & (my_recv != prev_recv)) & 0xffffffffull);
-    const unsigned half_mask = hh ? (start_mask >> 16) : (start_mask & 0xffffu);  // bit r: edge 16hh + r opens a segment
-    int my_rows[16];  // receiver of each of this half's edges
+    const unsigned sm = static_cast<unsigned>(__ballot((c > 0) & (my_recv != prev_recv)) & 0xffffffffull);
+    constexpr unsigned long long LO = 0x00000000ffffffffull, HI = 0xffffffff00000000ull;
+    float* const out_lane = a.out + 4 * c;
+    if (e0 + TE > a.M) {  // the one partial tile: its padding edges carry zeros
+      const int rows_valid = static_cast<int>(a.M - e0) - 16 * hh;
 #pragma unroll
-    for (int r = 0; r < 16; ++r) my_rows[r] = __shfl(my_recv, 16 * hh + r, 64);
-    float acc[4], first[4];
-    int closed = 0;  // segments closed so far in this half
+      for (int r = 0; r < 16; ++r)
 #pragma unroll
-    for (int jb = 0; jb < 4; ++jb) {
-      acc[jb] = w[jb][0] * xv[jb][0];
-      first[jb] = 0.0f;
+        for (int jb = 0; jb < 4; ++jb) xv[jb][r] = r < rows_valid ? xv[jb][r] : 0.0f;
     }
-    float* const out_col = a.out + c;
+    // features (4c, 4c+1) and (4c+2, 4c+3) as register pairs: v_pk_mul_f32 / v_pk_add_f32 do two columns per instruction
+    floatx2 acc01 = floatx2{w[0][0], w[1][0]} * floatx2{xv[0][0], xv[1][0]};
+    floatx2 acc23 = floatx2{w[2][0], w[3][0]} * floatx2{xv[2][0], xv[3][0]};
+    floatx2 first01 = {0.0f, 0.0f}, first23 = {0.0f, 0.0f};
+    unsigned had = 0;  // scalar: bit 0 / 1 = a segment has opened inside the low / high half
 #pragma unroll
     for (int r = 1; r < 16; ++r) {
-      const bool opens = (half_mask >> r) & 1u;
-      if (opens && closed > 0) {  // a segment strictly inside the half: exclusive to this tile
-        float* dst = out_col + static_cast<int64_t>(my_rows[r - 1]) * F;
-#pragma unroll
-        for (int jb = 0; jb < 4; ++jb) dst[jb * 32] = acc[jb];
+      const unsigned o = (sm >> r) & 0x10001u;  // bit 0: edge r opens a segment; bit 16: edge 16 + r does
+      const floatx2 m01 = floatx2{w[0][r], w[1][r]} * floatx2{xv[0][r], xv[1][r]};
+      const floatx2 m23 = floatx2{w[2][r], w[3][r]} * floatx2{xv[2][r], xv[3][r]};
+      if (o != 0) {
+        const bool o_lo = (o & 1u) != 0, o_hi = (o >> 16) != 0;
+        const unsigned long long open_mask = (o_lo ? LO : 0ull) | (o_hi ? HI : 0ull);
+        const unsigned long long store_mask = ((o_lo && (had & 1u)) ? LO : 0ull) | ((o_hi && (had & 2u)) ? HI : 0ull);
+        if (__builtin_amdgcn_inverse_ballot_w64(store_mask)) {
+          const int row_lo = __builtin_amdgcn_readlane(my_recv, r - 1);
+          const int row_hi = __builtin_amdgcn_readlane(my_recv, 16 + r - 1);
+          *reinterpret_cast<float4*>(out_lane + static_cast<int64_t>(hh ? row_hi : row_lo) * F) =
+              make_float4(acc01.x, acc01.y, acc23.x, acc23.y);
+        }
+        if (__builtin_amdgcn_inverse_ballot_w64(open_mask & ~store_mask)) {  // the half's first segment closes: keep it
+          first01 = acc01;
+          first23 = acc23;
+        }
+        if (__builtin_amdgcn_inverse_ballot_w64(open_mask)) {  // restart (the add below then yields m)
+          acc01 = floatx2{0.0f, 0.0f};
+          acc23 = floatx2{0.0f, 0.0f};
+        }
+        had |= (o_lo ? 1u : 0u) | (o_hi ? 2u : 0u);
       }
-#pragma unroll
-      for (int jb = 0; jb < 4; ++jb) {
-        const float m = w[jb][r] * xv[jb][r];
-        first[jb] = (opens && closed == 0) ? acc[jb] : first[jb];
-        acc[jb] = opens ? m : acc[jb] + m;
-      }
-      closed += opens ? 1 : 0;
+      acc01 += m01;
+      acc23 += m23;
     }
+    float acc[4] = {acc01.x, acc01.y, acc23.x, acc23.y};
+    float first[4] = {first01.x, first01.y, first23.x, first23.y};
     MP_STAMP(5)
     // wave-uniform shape of the tile
-    const int nlo = __builtin_popcount(start_mask & 0xfffeu) + 1;   // segments touching the low half
-    const int nhi = __builtin_popcount(start_mask >> 17) + 1;        // segments touching the high half
-    const bool cont = ((start_mask >> 16) & 1u) == 0;                // edge 16 continues the segment of edge 15
-    // hand the low half's open tail to the high half (lanes c+32) if the segment continues
-    float tail[4];
+    const int nlo = __builtin_popcount(sm & 0xfffeu) + 1;   // segments touching the low half
+    const int nhi = __builtin_popcount(sm >> 17) + 1;        // segments touching the high half
+    const bool cont = ((sm >> 16) & 1u) == 0;                // edge 16 continues the segment of edge 15
+    const int node_e0 = __builtin_amdgcn_readlane(my_recv, 0), node_e15 = __builtin_amdgcn_readlane(my_recv, 15);
+    const int node_e16 = __builtin_amdgcn_readlane(my_recv, 16), node_e31 = __builtin_amdgcn_readlane(my_recv, 31);
+    // Float atomics leave the XCD (device scope) and are paid per 128-B line touched: the lane's four features
+    // 4c..4c+3 are first transposed through 512 B of LDS so that each of the four atomic instructions of a half wave
+    // covers ONE contiguous line (features 32 jb + c) instead of four (measured: 3.3 us -> <1 us per launch at config 2).
+    float* const xs_half = Xs + (wave * 2 + hh) * F;
+    auto atomic_row = [&](int node, float v0, float v1, float v2, float v3) {
+      *reinterpret_cast<float4*>(xs_half + 4 * c) = make_float4(v0, v1, v2, v3);
+      float* dst = a.out + static_cast<int64_t>(node) * F + c;
 #pragma unroll
-    for (int jb = 0; jb < 4; ++jb) tail[jb] = __shfl_xor(acc[jb], 32, 64);  // in hi lanes: the low half's tail
+      for (int jb = 0; jb < 4; ++jb) atomicAdd(dst + jb * 32, xs_half[jb * 32 + c]);
+    };
+    auto store_row = [&](int node, float v0, float v1, float v2, float v3) {
+      *reinterpret_cast<float4*>(out_lane + static_cast<int64_t>(node) * F) = make_float4(v0, v1, v2, v3);
+    };
+    float tail[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+    if (cont) {  // hand the low half's open tail to the high half (lanes c + 32)
+#pragma unroll
+      for (int jb = 0; jb < 4; ++jb) tail[jb] = __shfl_xor(acc[jb], 32, 64);
+    }
     MP_STAMP(6)
     if (hh == 0) {
-      if (nlo > 1) {  // the tile's first segment closed inside the low half
-        float* dst = out_col + static_cast<int64_t>(__builtin_amdgcn_readlane(my_recv, 0)) * F;
-#pragma unroll
-        for (int jb = 0; jb < 4; ++jb) atomicAdd(dst + jb * 32, first[jb]);
-      }
+      if (nlo > 1) atomic_row(node_e0, first[0], first[1], first[2], first[3]);  // first segment closed in the low half
       if (!cont) {    // the low half's last segment ends at edge 15
-        float* dst = out_col + static_cast<int64_t>(__builtin_amdgcn_readlane(my_recv, 15)) * F;
-        if (nlo == 1) {
-#pragma unroll
-          for (int jb = 0; jb < 4; ++jb) atomicAdd(dst + jb * 32, acc[jb]);   // it is also the tile's first
-        } else {
-#pragma unroll
-          for (int jb = 0; jb < 4; ++jb) dst[jb * 32] = acc[jb];
-        }
+        if (nlo == 1) atomic_row(node_e15, acc[0], acc[1], acc[2], acc[3]);      // it is also the tile's first
+        else store_row(node_e15, acc[0], acc[1], acc[2], acc[3]);
       }
     } else {
       // the high half's first segment (the whole half if nhi == 1), plus the low half's tail when it continues
@@ -328,22 +368,9 @@ __global__ __launch_bounds__(WAVES * 64) void cfconv_fused_kernel(CfconvArgs a) 
         const float mine = nhi > 1 ? first[jb] : acc[jb];
         v0[jb] = cont ? tail[jb] + mine : mine;   // edge order: low-half part first
       }
-      {
-        float* dst = out_col + static_cast<int64_t>(__builtin_amdgcn_readlane(my_recv, 16)) * F;
-        const bool boundary = (cont && nlo == 1) || nhi == 1;   // contains the tile's first or last edge
-        if (boundary) {
-#pragma unroll
-          for (int jb = 0; jb < 4; ++jb) atomicAdd(dst + jb * 32, v0[jb]);
-        } else {
-#pragma unroll
-          for (int jb = 0; jb < 4; ++jb) dst[jb * 32] = v0[jb];
-        }
-      }
-      if (nhi > 1) {  // the tile's last segment
-        float* dst = out_col + static_cast<int64_t>(__builtin_amdgcn_readlane(my_recv, 31)) * F;
-#pragma unroll
-        for (int jb = 0; jb < 4; ++jb) atomicAdd(dst + jb * 32, acc[jb]);
-      }
+      if ((cont && nlo == 1) || nhi == 1) atomic_row(node_e16, v0[0], v0[1], v0[2], v0[3]);  // tile's first or last edge
+      else store_row(node_e16, v0[0], v0[1], v0[2], v0[3]);
+      if (nhi > 1) atomic_row(node_e31, acc[0], acc[1], acc[2], acc[3]);                     // the tile's last segment
     }
     MP_STAMP(7)
   }
@@ -358,8 +385,9 @@ __global__ __launch_bounds__(WAVES * 64) void cfconv_fused_kernel(CfconvArgs a) 
 
 constexpr int PACKED_FLOATS = MAX_KROWS * F + F * F + F;
 
-// LDS image of the filter-MLP weights: row k of W1 (k < B), the bias b1 as row B, zero rows up to MAX_KROWS, then W2,
-// every row stored [4*c + blk] = W[k][blk*32 + c]; finally b2 in natural order.
+// LDS image of the filter-MLP weights: row k of W1 (k < B), the bias b1 as row B, zero rows up to MAX_KROWS, each row
+// stored [4*c + blk] = W1[k][blk*32 + c]; then W2 and b2 in natural order (lane c of GEMM2 owns output features
+// 4c .. 4c+3, one per accumulator block).
 __global__ void cfconv_pack_kernel(const float* __restrict__ W1, const float* __restrict__ b1, int B,
                                    const float* __restrict__ W2, const float* __restrict__ b2,
                                    float* __restrict__ packed) {
@@ -372,8 +400,7 @@ __global__ void cfconv_pack_kernel(const float* __restrict__ W1, const float* __
       else if (k == B && b1) v = b1[col];
     } else if (i < MAX_KROWS * F + F * F) {
       const int j = i - MAX_KROWS * F;
-      const int k = j / F, col = (j % F) / 4 + 32 * (j % 4);
-      v = W2[k * F + col];
+      v = W2[j];
     } else {
       v = b2 ? b2[i - MAX_KROWS * F - F * F] : 0.0f;
     }
@@ -383,7 +410,7 @@ __global__ void cfconv_pack_kernel(const float* __restrict__ W1, const float* __
 
 template <int WAVES>
 size_t cfconv_lds_bytes() {
-  return sizeof(float) * (MAX_KROWS * F + F * F);
+  return sizeof(float) * (MAX_KROWS * F + F * F + WAVES * 2 * F);
 }
 
 template <int WAVES, bool GAUSS, bool FAST, int NKT, bool DIAG>

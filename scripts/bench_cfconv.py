@@ -3,10 +3,12 @@ import sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
 from gcnn_keras_amd import _ffi, synth
+if os.environ.get("MP_LIB"):  # A/B runs of two builds of the engine on the same box: MP_LIB=path/to/variant.so
+    _ffi.LIB_PATH = os.path.abspath(os.environ["MP_LIB"])
 from gcnn_keras_amd.engine import _HipTimer
 from gcnn_keras_amd.fused import FusedSchnet
 
-def run(graphs, flags_list=(1, 3, 5), iters=30):
+def run(graphs, flags_list=(1,), iters=100):
     b = synth.qm9_like_batch(num_graphs=graphs, seed=1234)
     p = synth.schnet_params(seed=7)
     for fl in flags_list:
