@@ -179,19 +179,25 @@ __global__ __launch_bounds__(WAVES * 64) void cfconv_fused_kernel(CfconvArgs a) 
     const int my_recv = nx_recv;
     const float d_mine = nx_d;
 
-    // ---- sender rows of this tile: issued first, consumed after GEMM2 (one 16-B read per lane and edge: a half wave reads one whole 512-B row) --------
+    // ---- sender rows of this tile (one 16-B read per lane and edge: a half wave reads one whole 512-B row).  With
+    //      one wave per SIMD they are requested first and consumed after GEMM2; with two waves per SIMD (WAVES = 8,
+    //      256 registers per wave) they are requested only after GEMM2 - the sibling wave's MFMAs cover the latency. ----
+    constexpr bool LATE_X = WAVES > 4;
     float xv[4][16];
+    auto load_sender_rows = [&]() {
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int row = rowmap(r, hh);               // MFMA row; its lane handles edge 16 hh + r
-      const int snode = __shfl(my_send, row, 64);
-      // always in range: padding rows reuse the last valid edge's sender
-      const float4 t = *reinterpret_cast<const float4*>(a.x + static_cast<int64_t>(snode) * F + 4 * c);
-      xv[0][r] = t.x;
-      xv[1][r] = t.y;
-      xv[2][r] = t.z;
-      xv[3][r] = t.w;
-    }
+      for (int r = 0; r < 16; ++r) {
+        const int row = rowmap(r, hh);               // MFMA row; its lane handles edge 16 hh + r
+        const int snode = __shfl(my_send, row, 64);
+        // always in range: padding rows reuse the last valid edge's sender
+        const float4 t = *reinterpret_cast<const float4*>(a.x + static_cast<int64_t>(snode) * F + 4 * c);
+        xv[0][r] = t.x;
+        xv[1][r] = t.y;
+        xv[2][r] = t.z;
+        xv[3][r] = t.w;
+      }
+    };
+    if constexpr (!LATE_X) load_sender_rows();
     prefetch_tile(tile0 + tile_step);  // next tile's edge data, in flight during this tile's GEMMs
 
     // ---- B operand of GEMM1: this lane's half of its edge's basis row (+ the constant 1 of the bias row) ----
@@ -272,6 +278,7 @@ __global__ __launch_bounds__(WAVES * 64) void cfconv_fused_kernel(CfconvArgs a) 
     }
 
     MP_STAMP(4)
+    if constexpr (LATE_X) load_sender_rows();
     // ---- multiply by the sender row and sum the segments IN REGISTERS.  Each lane half holds 16 consecutive edges
     //      (register order) of the lane's four feature columns.  The segment structure is wave-uniform data (one
     //      32-bit start mask from a ballot), so the walk is driven by SCALAR tests: a step without a boundary in either
@@ -445,11 +452,15 @@ int cfconv_dispatch(CfconvArgs args, bool gauss, int flags, hipStream_t s) {
   MP_REQUIRE(args.M < (int64_t{1} << 31), "mp_cfconv: M must fit int32");
   args.ntiles = static_cast<int>((args.M + TE - 1) / TE);
   const bool fast = (flags & 1) != 0;
-  // One workgroup per CU (the LDS holds the weights), persistent over the tiles; four waves = one per SIMD, each
-  // with a matrix pipe of its own.  An 8-wave build (two per SIMD, 256-VGPR cap, two-pass epilogue) exists behind
-  // flag bit 2; measured on MI355X it gains < 1 % at 2.5 M edges (the 4-wave kernel already keeps the pipe ~80 %
-  // busy at the clock the chip holds under this load) and loses at small M, so it is not selected automatically.
-  int waves = (flags & 4) ? 8 : 4;
+  // One workgroup per CU (the LDS holds the weights), persistent over the tiles.  FP32 MFMA and FP32 VALU share the
+  // SIMD's lanes, so a single wave per SIMD leaves the matrix pipe idle during its own vector phases (softplus,
+  // segment walk); a second wave per SIMD fills those gaps once the waves run out of step, i.e. when every wave has
+  // several tiles: 8 waves (256 registers each, sender rows loaded late) from 4096 tiles on - measured 812 vs 928 us at
+  // 2.5 M edges, 87 vs 93 us at 0.2 M - and 4 waves (one tile per wave spread over more CUs) below.  Flag bit 2 forces
+  // 8 waves, bit 3 forces 4.
+  int waves = args.ntiles >= 4096 ? 8 : 4;
+  if (flags & 4) waves = 8;
+  if (flags & 8) waves = 4;
   int grid = (args.ntiles + waves - 1) / waves;
   if (grid > 256) grid = 256;
   if (args.diag) {

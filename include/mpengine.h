@@ -197,7 +197,8 @@ int mp_edge_prepare_i64_f32(const int64_t* idx, int64_t M, const int64_t* node_s
  * The filter-MLP weights (Keras layouts W1 (B,128), b1 (128)|NULL, W2 (128,128), b2 (128)|NULL) are packed once
  * per weight update into the kernel's LDS image by mp_cfconv_pack_f32 (mp_cfconv_packed_floats() floats).
  * recv_sorted ascending; perm (nullable) maps sorted position -> original edge (rbf / send are in original
- * order); out (N,128) must be zero on entry.  flags bit0: fast softplus (v_exp/v_log form, |delta| < 2e-7). */
+ * order); out (N,128) must be zero on entry.  flags bit0: fast softplus (v_exp/v_log form, |delta| < 2e-7);
+ * bit2 / bit3 force the 8-wave / 4-wave workgroup (default: by tile count). */
 int mp_cfconv_packed_floats(void);
 int mp_cfconv_pack_f32(const float* W1, const float* b1, int B, const float* W2, const float* b2, float* packed,
                        mpStream_t stream);
