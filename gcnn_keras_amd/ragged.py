@@ -173,6 +173,29 @@ class IndexPlan:
             self._csr[(0, False)] = self._csr[(0, True)] = (csr_ptr, None, cols[0, :self.M])
         return self
 
+    @classmethod
+    def from_host(cls, idx, nodes, plan, stream=None):
+        """Plan computed by the host packer (``mp_pack_edge_index_host``) while it concatenated the batch: the shifted
+        columns, flag word and CSR arrive with the batch instead of being recomputed by ``mp_index_prepare_i64``."""
+        import ctypes
+        self = cls.__new__(cls)
+        self.M, self.K, self.N, self.G = plan["M"], plan["K"], plan["N"], idx.nrows()
+        dev = idx.values.device
+        st = _ffi.stream() if stream is None else stream
+        self.cols = torch.empty((self.K, max(self.M, 1)), dtype=torch.int32, device=dev)
+        if self.M:
+            _ffi.call("mp_memcpy_h2d_async", _ffi.ptr(self.cols), plan["cols"].ctypes.data_as(ctypes.c_void_p),
+                      self.K * self.M * 4, st)
+        self.flags = torch.full((1,), plan["flags"], dtype=torch.int32, device=dev)
+        self._flags_host = plan["flags"]
+        self._csr = {}
+        if plan.get("csr") is not None and not (plan["flags"] & _ffi.MP_FLAG_UNSORTED_COL0):
+            ptr = torch.empty(self.N + 1, dtype=torch.int32, device=dev)
+            _ffi.call("mp_memcpy_h2d_async", _ffi.ptr(ptr), plan["csr"].ctypes.data_as(ctypes.c_void_p),
+                      (self.N + 1) * 4, st)
+            self._csr[(0, False)] = self._csr[(0, True)] = (ptr, None, self.cols[0, :self.M])
+        return self
+
     def flags_host(self):
         if self._flags_host is None:
             self._flags_host = int(self.flags.item())

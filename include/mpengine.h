@@ -48,6 +48,9 @@ enum mp_binary_op { MP_ADD = 0, MP_SUB = 1, MP_MUL = 2 };
 /* bits of the device flag word written by mp_index_prepare_i64 */
 enum mp_index_flag { MP_FLAG_OOB = 1, MP_FLAG_UNSORTED_COL0 = 2, MP_FLAG_UNSORTED_COL1 = 4 };
 
+/* element types of the host packer (mp_pack_*_host) */
+enum mp_dtype { MP_DT_F32 = 0, MP_DT_F64 = 1, MP_DT_I32 = 2, MP_DT_I64 = 3 };
+
 /* ---------------------------------------------------------------- runtime -------------------------------- */
 const char* mp_last_error(void);
 int mp_version(void);
@@ -281,6 +284,33 @@ int mp_bessel_basis_grad_f32(const float* d, int64_t M, const float* frequencies
 int mp_gauss_basis_grad_f32(const float* d, int64_t M, int bins, float distance, float sigma, float offset,
                             const float* gy, float* gd, mpStream_t stream);                         /* geom.py:567-571 */
 int mp_cos_cutoff_grad_f32(const float* d, int64_t n, float cutoff, const float* gy, float* gd, mpStream_t stream);
+
+/* ---------------------------------------------------------------- host batch packer ---------------------- */
+/* The data-format side of the path.  Host pointers only; nothing here launches a kernel.
+ *
+ * mp_pack_rows_host = kgcnn.data.utils.ragged_tensor_from_nested_numpy (kgcnn/data/utils.py:129-157:
+ * np.concatenate(list, axis=0, dtype) + row lengths), as called per property by MemoryGraphList.tensor
+ * (kgcnn/data/base.py:203-239): rows_host[g] points to counts_host[g] rows of row_elems elements of src_kind; they
+ * are concatenated (converted to dst_kind: f64<->f32, i32<->i64, i32/i64->f32) into dst_host, and the int64
+ * row_splits (G+1) are written.  Multi-threaded over contiguous graph ranges (threads <= 1: caller's thread). */
+int mp_pack_rows_host(const void* const* rows_host, const int64_t* counts_host, int64_t G, int64_t row_elems,
+                      int src_kind, int dst_kind, void* dst_host, int64_t* splits_out_host, int threads);
+
+/* Edge indices of a batch: concatenates the per-graph (m_g, K) sample index lists (idx_kind MP_DT_I64 | MP_DT_I32)
+ * into the API's int64 (M,K) tensor and, in the same pass, produces what mp_index_prepare_i64 +
+ * mp_csr_from_sorted_i32 would compute on the device for this batch: shifted int32 columns cols[k*M + e]
+ * (kgcnn/ops/partition.py:140-155), the MP_FLAG_* word, and - if csr_ptr_out_host is given and column 0 is sorted -
+ * the CSR offsets ptr[0..N] (zeros otherwise).  Also writes both row_splits (G+1 each). */
+int mp_pack_edge_index_host(const void* const* idx_rows_host, int idx_kind, const int64_t* edge_counts_host,
+                            const int64_t* node_counts_host, int64_t G, int K, int64_t* idx_out_host,
+                            int64_t* edge_splits_out_host, int64_t* node_splits_out_host, int32_t* cols_out_host,
+                            int32_t* csr_ptr_out_host, int32_t* flags_out_host, int threads);
+
+/* Staging memory for the packer (pinned = hipHostMalloc: needs a device; 0 = aligned malloc) and the asynchronous
+ * host-to-device copy that hands a packed tensor to the engine on the caller's stream. */
+int mp_host_alloc(size_t bytes, int pinned, void** out_host);
+int mp_host_free(void* p, int pinned);
+int mp_memcpy_h2d_async(void* dst_device, const void* src_host, size_t bytes, mpStream_t stream);
 
 #ifdef __cplusplus
 }

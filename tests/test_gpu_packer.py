@@ -1,0 +1,77 @@
+"""Batch packer -> device: the packed tensors and the host-built index plan must be indistinguishable from the ones the
+engine makes from ``RaggedTensor.from_numpy`` + ``mp_index_prepare_i64`` (bit-exact), and a model fed by the packer must
+return the same bits."""
+import numpy as np
+import pytest
+import torch
+
+from gcnn_keras_amd import synth
+
+pytestmark = pytest.mark.gpu
+
+ITEMS = [{"name": "node_number", "ragged": True, "dtype": "float32"},
+         {"name": "node_coordinates", "ragged": True, "dtype": "float32"},
+         {"name": "edge_indices", "ragged": True, "dtype": "int64"}]
+
+
+def _graphs(b):
+    ns, es = b["node_splits"], b["edge_splits"]
+    return [{"node_number": b["node_number"][ns[i]:ns[i + 1]],
+             "node_coordinates": b["node_coordinates"][ns[i]:ns[i + 1]].astype(np.float64),   # converted by the packer
+             "edge_indices": b["edge_indices"][es[i]:es[i + 1]]} for i in range(len(ns) - 1)]
+
+
+@pytest.mark.parametrize("num_graphs,seed", [(5, 3), (128, 1234)])
+def test_packed_batch_equals_from_numpy(num_graphs, seed):
+    from gcnn_keras_amd.data import BatchPacker
+    from gcnn_keras_amd.ragged import RaggedTensor
+    b = synth.qm9_like_batch(num_graphs=num_graphs, seed=seed)
+    packer = BatchPacker(ITEMS, index_item="edge_indices", node_item="node_number")
+    batch = packer.pack(_graphs(b)).wait()
+    for key, vals, splits in (("node_number", b["node_number"], b["node_splits"]),
+                              ("node_coordinates", b["node_coordinates"], b["node_splits"]),
+                              ("edge_indices", b["edge_indices"], b["edge_splits"])):
+        assert np.array_equal(batch[key].values.cpu().numpy(), vals)
+        assert np.array_equal(batch[key].row_splits.cpu().numpy(), splits)
+    # host-built plan == device-built plan
+    nodes = RaggedTensor.from_numpy(b["node_number"], b["node_splits"])
+    idx = RaggedTensor.from_numpy(b["edge_indices"], b["edge_splits"])
+    dev_plan = idx.index_plan(nodes)
+    host_plan = batch["edge_indices"].index_plan(batch["node_number"])
+    assert host_plan is not dev_plan
+    assert torch.equal(host_plan.cols[:, :host_plan.M], dev_plan.cols[:, :dev_plan.M])
+    assert host_plan.flags_host() == dev_plan.flags_host()
+    hp, hperm, _ = host_plan.csr(0)
+    dp, dperm, _ = dev_plan.csr(0)
+    assert hperm is None and dperm is None and torch.equal(hp, dp)
+
+
+def test_model_on_packed_batches_double_buffered():
+    from gcnn_keras_amd.data import BatchPacker
+    from gcnn_keras_amd.literature import Schnet
+    from gcnn_keras_amd.ragged import RaggedTensor
+    p = synth.schnet_params(seed=7, random_bias=True)
+    model = Schnet.make_model(depth=3)
+    model.set_weights(list(p.values()))
+    packer = BatchPacker(ITEMS, index_item="edge_indices", node_item="node_number")
+    batches = [synth.qm9_like_batch(num_graphs=g, seed=s) for g, s in ((6, 11), (9, 12), (4, 13), (12, 14))]
+    packed = []
+    for b in batches:                     # four batches through two staging slots
+        packed.append(packer.pack(_graphs(b)))
+    for b, pk in zip(batches, packed):
+        pk.wait()
+        got = model([pk["node_number"], pk["node_coordinates"], pk["edge_indices"]]).cpu().numpy()
+        ref = model([RaggedTensor.from_numpy(b["node_number"], b["node_splits"]),
+                     RaggedTensor.from_numpy(b["node_coordinates"], b["node_splits"]),
+                     RaggedTensor.from_numpy(b["edge_indices"], b["edge_splits"])]).cpu().numpy()
+        assert np.array_equal(got, ref)
+
+
+def test_ragged_tensor_from_nested_numpy_reference_example():
+    # docstring example of the reference, kgcnn/data/utils.py:138-145
+    from gcnn_keras_amd.data import ragged_tensor_from_nested_numpy
+    rt = ragged_tensor_from_nested_numpy([np.array([[0]]), np.array([[1], [2], [3]])])
+    assert rt.shape == (2, None, 1)
+    assert [r.tolist() for r in rt.numpy_rows()] == [[[0]], [[1], [2], [3]]]
+    with pytest.raises(ValueError):
+        ragged_tensor_from_nested_numpy([np.zeros((1, 1))], row_splits_dtype="int32")
