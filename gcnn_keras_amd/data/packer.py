@@ -105,6 +105,7 @@ def to_device(values, splits, device="cuda", stream=None):
     _ffi.call("mp_memcpy_h2d_async", _ffi.ptr(dev_splits), splits.ctypes.data_as(ctypes.c_void_p), splits.nbytes, st)
     out = RaggedTensor(dev_vals, dev_splits)
     out._splits_host = splits.copy()
+    out._staging_view = values  # valid until this staging slot is packed again (used for topology signatures)
     return out
 
 

@@ -139,27 +139,32 @@ class SchnetForward:
 
 
 class GraphedModel:
-    """Replay a layer-path model (any ``make_model`` result, or an ``EnergyForceModel``-free forward) from one HIP graph.
+    """Replay a layer-path model (any ``make_model`` result, or an ``EnergyForceModel``) from one HIP graph.
 
-    The layer path issues ~100 engine calls per forward; at QM9/MD17 batch sizes the host cannot keep the GPU busy.
-    ``GraphedModel(model, inputs)`` runs the forward once eagerly (which builds and caches the index plans on the given
-    ragged inputs, so no host synchronisation is left), then captures the same call sequence - every launch goes through
-    the C ABI on the capture stream, intermediate buffers come from the graph's private pool - and ``__call__()``
-    replays it.  The graph is bound to the input buffers and to the batch's index structure: refresh feature /
-    coordinate *values* in place (``inputs[i].values.copy_(...)``) between replays; a new edge list needs a new graph.
+    The layer path issues ~100 engine calls per forward (several hundred with the reverse pass of an
+    ``EnergyForceModel``); at QM9/MD17 batch sizes the host cannot keep the GPU busy.  ``GraphedModel(model, inputs)``
+    runs the call eagerly (which builds and caches the index plans on the given ragged inputs, so no host
+    synchronisation is left), then captures the same call sequence - every launch goes through the C ABI on the capture
+    stream, intermediate buffers come from the graph's private pool - and ``__call__()`` replays it.  With
+    ``grad=True`` (default for an ``EnergyForceModel``) the capture includes the reverse pass that produces the forces.
+    The graph is bound to the input buffers and to the batch's index structure: refresh feature / coordinate *values*
+    in place (``inputs[i].values.copy_(...)``) between replays; a new edge list needs a new graph.
     """
 
-    def __init__(self, model, inputs):
+    def __init__(self, model, inputs, grad=None):
         if not torch.cuda.is_available():
             raise _ffi.EngineError("GraphedModel needs an MI355X (no CPU fallback)")
-        self.model, self.inputs = model, inputs
+        if grad is None:
+            grad = hasattr(model, "energy_model")
+        self.model, self.inputs, self.grad = model, inputs, bool(grad)
         self.stream = torch.cuda.Stream()
-        with torch.cuda.stream(self.stream), torch.no_grad():
-            model(inputs)
-            model(inputs)
+        self.stream.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(self.stream), torch.set_grad_enabled(self.grad):
+            for _ in range(3):
+                model(inputs)
         torch.cuda.synchronize()
         self.graph = torch.cuda.CUDAGraph()
-        with torch.no_grad(), torch.cuda.graph(self.graph, stream=self.stream):
+        with torch.set_grad_enabled(self.grad), torch.cuda.graph(self.graph, stream=self.stream):
             self.output = model(inputs)
         torch.cuda.synchronize()
 

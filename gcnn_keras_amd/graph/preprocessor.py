@@ -33,7 +33,18 @@ class SetRange:
     def get_config(self):
         return {"name": self.name, **self._config_kwargs}
 
-    def __call__(self, node_coordinates: RaggedTensor):
+    @property
+    def produces(self):
+        """Property names this preprocessor adds when used on a dict of packed tensors (MD driver)."""
+        return (self._config_kwargs["range_indices"], self._config_kwargs["range_attributes"])
+
+    def __call__(self, node_coordinates):
+        if isinstance(node_coordinates, dict):  # dict of packed device tensors -> dict of the new properties
+            idx, attr = self._run(node_coordinates[self._config_kwargs["node_coordinates"]])
+            return {self._config_kwargs["range_indices"]: idx, self._config_kwargs["range_attributes"]: attr}
+        return self._run(node_coordinates)
+
+    def _run(self, node_coordinates: RaggedTensor):
         """``node_coordinates``: ragged ``(batch, [N], 3)`` float32.  Returns ``(range_indices, range_attributes)``:
         ragged ``(batch, [M], 2)`` int64 sample indices and ragged ``(batch, [M], 1)`` distances; the returned index
         tensor carries a ready index plan (int32 ids + receiver CSR), so the first gather / pooling costs nothing."""
