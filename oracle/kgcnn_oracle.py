@@ -805,6 +805,76 @@ def gcn_forward(params, node_attr, edge_weights, idx, depth=3, act="relu", pooli
 
 
 # ----------------------------------------------------------------------------------------
+# kgcnn/layers/conv/gin_conv.py, gat_conv.py, dmpnn_conv.py (callers of the same primitives)
+# ----------------------------------------------------------------------------------------
+
+def gin_layer(node, idx, eps=0.0, pooling_method="sum"):
+    """``GIN.call``, kgcnn/layers/conv/gin_conv.py:65-69."""
+    ed = gather_nodes_outgoing(node, idx)
+    nu = pooling_local_edges(node, ed, idx, pooling_method=pooling_method)
+    no = (np.asarray(1, node.values.dtype) + np.asarray(eps, node.values.dtype)) * node.values
+    return R(no + nu.values, node.row_splits)
+
+
+def gine_layer(node, idx, edges, eps=0.0, pooling_method="sum", act="relu"):
+    """``GINE.call``, kgcnn/layers/conv/gin_conv.py:147-153."""
+    ed = gather_nodes_outgoing(node, idx)
+    ed = R(activation(act, ed.values + edges.values), ed.row_splits)
+    nu = pooling_local_edges(node, ed, idx, pooling_method=pooling_method)
+    no = (np.asarray(1, node.values.dtype) + np.asarray(eps, node.values.dtype)) * node.values
+    return R(no + nu.values, node.row_splits)
+
+
+def attention_head_gat(node, edge, idx, p, act="kgcnn>leaky_relu", use_edge_features=False, use_final_activation=True):
+    """``AttentionHeadGAT.call``, kgcnn/layers/conv/gat_conv.py:103-118.  ``p``: linear_trafo/{kernel,bias},
+    alpha/kernel."""
+    w_n = dense(node, p["linear_trafo/kernel"], p.get("linear_trafo/bias"), "linear")
+    wn_in = gather_nodes_ingoing(w_n, idx)
+    wn_out = gather_nodes_outgoing(w_n, idx)
+    parts = [wn_in, wn_out, edge] if use_edge_features else [wn_in, wn_out]
+    a_ij = dense(lazy_concatenate(parts, axis=-1), p["alpha/kernel"], None, act)
+    h_i = pooling_local_edges_attention(node, wn_out, a_ij, idx)
+    if use_final_activation:
+        h_i = R(activation(act, h_i.values), h_i.row_splits)
+    return h_i
+
+
+def attention_head_gatv2(node, edge, idx, p, act="kgcnn>leaky_relu", use_edge_features=False,
+                         use_final_activation=True):
+    """``AttentionHeadGATV2.call``, kgcnn/layers/conv/gat_conv.py:200-218.  ``p``: linear_trafo/{kernel,bias},
+    alpha_activation/{kernel,bias}, alpha/kernel."""
+    w_n = dense(node, p["linear_trafo/kernel"], p.get("linear_trafo/bias"), "linear")
+    n_in = gather_nodes_ingoing(node, idx)
+    n_out = gather_nodes_outgoing(node, idx)
+    wn_out = gather_nodes_outgoing(w_n, idx)
+    parts = [n_in, n_out, edge] if use_edge_features else [n_in, n_out]
+    a_ij = dense(lazy_concatenate(parts, axis=-1), p["alpha_activation/kernel"], p.get("alpha_activation/bias"), act)
+    a_ij = dense(a_ij, p["alpha/kernel"], None, "linear")
+    h_i = pooling_local_edges_attention(node, wn_out, a_ij, idx)
+    if use_final_activation:
+        h_i = R(activation(act, h_i.values), h_i.row_splits)
+    return h_i
+
+
+def dmpnn_gather_edges_pairs(edges, pair_index):
+    """``DMPNNGatherEdgesPairs.call``, kgcnn/layers/conv/dmpnn_conv.py:39-46: reverse-edge rows, zeros where the pair
+    index is negative."""
+    pairs = np.asarray(pair_index.values)
+    safe = R(np.where(pairs >= 0, pairs, np.zeros_like(pairs)), pair_index.row_splits)
+    gathered = gather_nodes_ingoing(edges, safe)
+    keep = (pairs[:, 0] >= 0).reshape((-1,) + (1,) * (gathered.values.ndim - 1))
+    return R(np.where(keep, gathered.values, np.zeros_like(gathered.values)), gathered.row_splits)
+
+
+def dmpnn_pooling_edges_directed(nodes, edges, idx, reverse_pair):
+    """``DMPNNPPoolingEdgesDirected.call``, kgcnn/layers/conv/dmpnn_conv.py:83-87."""
+    pool_edge_receive = pooling_local_edges(nodes, edges, idx, pooling_method="sum")
+    ed_new = gather_nodes_outgoing(pool_edge_receive, idx)
+    ed_not = dmpnn_gather_edges_pairs(edges, reverse_pair)
+    return R(ed_new.values - ed_not.values, ed_new.row_splits)
+
+
+# ----------------------------------------------------------------------------------------
 # kgcnn/layers/casting.py
 # ----------------------------------------------------------------------------------------
 

@@ -1,0 +1,174 @@
+"""Other conv families on the same primitives: GIN / GINE, GAT / GATv2 attention heads, DMPNN edge
+pooling - engine layers vs the CPU oracle.  Tolerance 1e-5 of the output scale (float sums / softmax), exact for the
+DMPNN pair gather.  Parity unpinned by the reference except ``DMPNNGatherEdgesPairs`` (test/test_conv_dmpnn.py) and the
+attention pooling underneath the GAT heads (test/test_conv_attention.py), see tests/test_oracle_pins.py."""
+import numpy as np
+import pytest
+import torch
+
+from gcnn_keras_amd import synth
+from oracle import kgcnn_oracle as ko
+
+pytestmark = pytest.mark.gpu
+
+
+def _dev(values, splits):
+    from gcnn_keras_amd.ragged import RaggedTensor
+    return RaggedTensor.from_numpy(values, splits)
+
+
+def _batch(num_graphs=9, seed=3, f=32, fe=32):
+    b = synth.qm9_like_batch(num_graphs=num_graphs, seed=seed)
+    rng = np.random.default_rng(seed + 100)
+    n, m = int(b["node_splits"][-1]), int(b["edge_splits"][-1])
+    b["x"] = rng.normal(size=(n, f)).astype(np.float32)
+    b["e"] = rng.normal(size=(m, fe)).astype(np.float32)
+    return b
+
+
+def _close(got, ref, tol=1e-5):
+    scale = max(float(np.max(np.abs(ref))), 1e-30)
+    assert got.shape == ref.shape
+    assert np.max(np.abs(got - ref)) <= tol * scale, (np.max(np.abs(got - ref)), scale)
+
+
+@pytest.mark.parametrize("pooling", ["sum", "mean", "max"])
+def test_gin(pooling):
+    from gcnn_keras_amd.layers.conv.gin_conv import GIN
+    b = _batch()
+    layer = GIN(pooling_method=pooling, epsilon_learnable=True)
+    layer.set_weights([np.float32(0.25)])
+    out = layer([_dev(b["x"], b["node_splits"]), _dev(b["edge_indices"], b["edge_splits"])])
+    ref = ko.gin_layer(ko.R(b["x"], b["node_splits"]), ko.R(b["edge_indices"], b["edge_splits"]), eps=0.25,
+                       pooling_method=pooling)
+    _close(out.values.cpu().numpy(), ref.values)
+    assert layer.get_config()["pooling_method"] == pooling and layer.get_config()["epsilon_learnable"] is True
+
+
+def test_gin_fused_equals_layered_and_unsorted_edges():
+    from gcnn_keras_amd.layers.conv.gin_conv import GIN
+    b = _batch(num_graphs=5, seed=8)
+    rng = np.random.default_rng(0)
+    # shuffle the edges inside each graph: the stable-sort path of PoolingLocalEdges (pooling.py:65-68)
+    idx = b["edge_indices"].copy()
+    es = b["edge_splits"]
+    for g in range(len(es) - 1):
+        idx[es[g]:es[g + 1]] = idx[es[g]:es[g + 1]][rng.permutation(es[g + 1] - es[g])]
+    layer = GIN()
+    node, index = _dev(b["x"], b["node_splits"]), _dev(idx, es)
+    fused = layer([node, index]).values.cpu().numpy()
+    pooled = layer.lay_pool([node, layer.lay_gather([node, index]), index])
+    layered = (node.values + pooled.values).cpu().numpy()
+    assert np.array_equal(fused, layered)        # same accumulation order in both routes
+    ref = ko.gin_layer(ko.R(b["x"], b["node_splits"]), ko.R(idx, es))
+    _close(fused, ref.values)
+
+
+def test_gine():
+    from gcnn_keras_amd.layers.conv.gin_conv import GINE
+    b = _batch()
+    layer = GINE(activation="relu")
+    out = layer([_dev(b["x"], b["node_splits"]), _dev(b["edge_indices"], b["edge_splits"]),
+                 _dev(b["e"], b["edge_splits"])])
+    ref = ko.gine_layer(ko.R(b["x"], b["node_splits"]), ko.R(b["edge_indices"], b["edge_splits"]),
+                        ko.R(b["e"], b["edge_splits"]))
+    _close(out.values.cpu().numpy(), ref.values)
+    assert layer.get_config()["activation"] == "relu"
+
+
+@pytest.mark.parametrize("use_edges", [False, True])
+def test_attention_head_gat(use_edges):
+    from gcnn_keras_amd.layers.conv.gat_conv import AttentionHeadGAT
+    b = _batch(f=16, fe=8)
+    rng = np.random.default_rng(5)
+    units = 24
+    p = {"linear_trafo/kernel": synth.glorot_uniform(rng, 16, units),
+         "linear_trafo/bias": rng.normal(size=units).astype(np.float32) * 0.1,
+         "alpha/kernel": synth.glorot_uniform(rng, 2 * units + (8 if use_edges else 0), 1)}
+    layer = AttentionHeadGAT(units, use_edge_features=use_edges)
+    inputs = [_dev(b["x"], b["node_splits"]), _dev(b["e"], b["edge_splits"]),
+              _dev(b["edge_indices"], b["edge_splits"])]
+    layer(inputs)   # build
+    layer.set_weights([p["linear_trafo/kernel"], p["linear_trafo/bias"], p["alpha/kernel"]])
+    out = layer(inputs)
+    ref = ko.attention_head_gat(ko.R(b["x"], b["node_splits"]), ko.R(b["e"], b["edge_splits"]),
+                                ko.R(b["edge_indices"], b["edge_splits"]), p, use_edge_features=use_edges)
+    assert tuple(out.values.shape) == (len(b["x"]), units)
+    _close(out.values.cpu().numpy(), ref.values, tol=2e-5)
+    cfg = layer.get_config()
+    assert cfg["units"] == units and cfg["use_edge_features"] is use_edges and cfg["activation"] == "kgcnn>leaky_relu"
+
+
+def test_attention_head_gat_reference_shape_case():
+    # reference test/test_conv_attention.py:46-56: AttentionHeadGAT(5) on the two-molecule fixture -> (8, 5) rows
+    from gcnn_keras_amd.layers.conv.gat_conv import AttentionHeadGAT
+    from gcnn_keras_amd.ragged import RaggedTensor
+    n1 = [[[1.0], [6.0], [1.0], [6.0], [1.0], [1.0], [6.0], [6.0]], [[6.0], [1.0], [1.0]]]
+    ei1 = [[[0, 1], [1, 0], [1, 6], [2, 3], [3, 2], [3, 5], [3, 7], [4, 7], [5, 3], [6, 1], [6, 7], [7, 3], [7, 4],
+            [7, 6]], [[0, 1], [1, 0], [2, 0]]]
+    e1 = [[[0.4]] * 14, [[0.25]] * 3]
+    n = RaggedTensor.from_nested(n1, np.float32, (1,))
+    edi = RaggedTensor.from_nested(ei1, np.int64, (2,))
+    ed = RaggedTensor.from_nested(e1, np.float32, (1,))
+    result = AttentionHeadGAT(5)([n, ed, edi])
+    assert tuple(result[0].shape) == (8, 5)
+
+
+@pytest.mark.parametrize("use_edges", [False, True])
+def test_attention_head_gatv2(use_edges):
+    from gcnn_keras_amd.layers.conv.gat_conv import AttentionHeadGATV2
+    b = _batch(f=16, fe=8)
+    rng = np.random.default_rng(6)
+    units = 24
+    fin = 2 * 16 + (8 if use_edges else 0)
+    p = {"linear_trafo/kernel": synth.glorot_uniform(rng, 16, units),
+         "linear_trafo/bias": rng.normal(size=units).astype(np.float32) * 0.1,
+         "alpha_activation/kernel": synth.glorot_uniform(rng, fin, units),
+         "alpha_activation/bias": rng.normal(size=units).astype(np.float32) * 0.1,
+         "alpha/kernel": synth.glorot_uniform(rng, units, 1)}
+    layer = AttentionHeadGATV2(units, use_edge_features=use_edges, use_final_activation=False)
+    inputs = [_dev(b["x"], b["node_splits"]), _dev(b["e"], b["edge_splits"]),
+              _dev(b["edge_indices"], b["edge_splits"])]
+    layer(inputs)
+    layer.set_weights(list(p.values()))
+    out = layer(inputs)
+    ref = ko.attention_head_gatv2(ko.R(b["x"], b["node_splits"]), ko.R(b["e"], b["edge_splits"]),
+                                  ko.R(b["edge_indices"], b["edge_splits"]), p, use_edge_features=use_edges,
+                                  use_final_activation=False)
+    _close(out.values.cpu().numpy(), ref.values, tol=2e-5)
+
+
+def _reverse_pairs(idx, splits):
+    out = np.full((len(idx), 1), -1, dtype=np.int64)
+    for g in range(len(splits) - 1):
+        pos = {(int(i), int(j)): k for k, (i, j) in enumerate(idx[splits[g]:splits[g + 1]])}
+        for k, (i, j) in enumerate(idx[splits[g]:splits[g + 1]]):
+            out[splits[g] + k, 0] = pos.get((int(j), int(i)), -1)
+    return out
+
+
+def test_dmpnn_layers():
+    from gcnn_keras_amd.layers.conv.dmpnn_conv import DMPNNGatherEdgesPairs, DMPNNPPoolingEdgesDirected
+    b = _batch(num_graphs=6, seed=12, fe=32)
+    pairs = _reverse_pairs(b["edge_indices"], b["edge_splits"])
+    pairs[::7] = -1                               # some edges without a reverse partner
+    edges, pair_index = _dev(b["e"], b["edge_splits"]), _dev(pairs, b["edge_splits"])
+    got = DMPNNGatherEdgesPairs()([edges, pair_index]).values.cpu().numpy()
+    ref = ko.dmpnn_gather_edges_pairs(ko.R(b["e"], b["edge_splits"]), ko.R(pairs, b["edge_splits"])).values
+    assert np.array_equal(got, ref)
+    out = DMPNNPPoolingEdgesDirected()([_dev(b["x"], b["node_splits"]), edges,
+                                        _dev(b["edge_indices"], b["edge_splits"]), pair_index])
+    ref = ko.dmpnn_pooling_edges_directed(ko.R(b["x"], b["node_splits"]), ko.R(b["e"], b["edge_splits"]),
+                                          ko.R(b["edge_indices"], b["edge_splits"]), ko.R(pairs, b["edge_splits"]))
+    _close(out.values.cpu().numpy(), ref.values)
+
+
+def test_dmpnn_reference_case():
+    # reference test/test_conv_dmpnn.py:11-28
+    from gcnn_keras_amd.layers.conv.dmpnn_conv import DMPNNGatherEdgesPairs
+    from gcnn_keras_amd.ragged import RaggedTensor
+    e1 = [[[0.0, 0.0], [1.0, 1.0], [2.0, 2.0], [3.0, 3.0]], [[0.0, 0.0], [1.0, 1.0], [2.0, 2.0], [3.0, 3.0]]]
+    pairs = [[[1], [0], [3], [2]], [[-1], [2], [1], [-1]]]
+    result = DMPNNGatherEdgesPairs()([RaggedTensor.from_nested(e1, np.float32, (2,)),
+                                      RaggedTensor.from_nested(pairs, np.int64, (1,))])
+    assert np.amax(np.abs(result[0].cpu().numpy() - np.array([[1.0, 1.0], [0.0, 0.0], [3.0, 3.0], [2.0, 2.0]]))) < 1e-4

@@ -65,3 +65,17 @@ def test_lstm_pool_shape_case_segment_rows():
     edges = ko.ragged_from_row_lengths(np.ones((42, 3), np.float32), [14, 28])
     out = ko.pooling_local_edges(node, edges, idx, "sum")
     assert ko.ragged_rows(out)[0].shape == (8, 3)
+
+
+def test_dmpnn_gather_edges_pairs_reference_case():
+    # reference test/test_conv_dmpnn.py:11-28: edges gathered at their reverse pairs; the reverse-pair indices of
+    # ei1[0] = [[0,1],[1,0],[1,2],[2,1]] are [1, 0, 3, 2] (set_edge_indices_reverse)
+    e1 = [np.array([[0.0, 0.0], [1.0, 1.0], [2.0, 2.0], [3.0, 3.0], [4.0, 4.0]]),
+          np.array([[0.0, 0.0], [1.0, 1.0], [2.0, 2.0], [3.0, 3.0]])]
+    pairs = [np.array([[1], [0], [3], [2], [-1]]), np.array([[-1], [2], [1], [-1]])]
+    edges = ko.ragged_from_list(e1, np.float32, (2,))
+    pair_index = ko.ragged_from_list(pairs, np.int64, (1,))
+    out = ko.ragged_rows(ko.dmpnn_gather_edges_pairs(edges, pair_index))
+    assert np.max(np.abs(out[0][:4] - np.array([[1.0, 1.0], [0.0, 0.0], [3.0, 3.0], [2.0, 2.0]]))) < 1e-4
+    assert np.array_equal(out[0][4], [0.0, 0.0])                      # no reverse edge -> zeros (dmpnn_conv.py:44-46)
+    assert np.array_equal(out[1], [[0.0, 0.0], [2.0, 2.0], [1.0, 1.0], [0.0, 0.0]])
