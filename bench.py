@@ -107,11 +107,18 @@ def main():
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--graphs", type=int, default=128, help="graphs per GPU (BASELINE config 2 = 128)")
     ap.add_argument("--mode", default="auto", choices=["auto", "fused", "layers"])
+    ap.add_argument("--in-flight", type=int, default=4,
+                    help="independent batch slots (own buffers + HIP stream + graph) whose forwards overlap on the GPU; "
+                         "1 = strictly one forward at a time")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="nccl = RCCL over xGMI (production); gloo only rehearses N > 1 on a single-GPU box")
     args = ap.parse_args()
 
+    # Several forwards are kept in flight on separate HIP streams (--in-flight); ROCm maps streams onto 4 hardware queues
+    # by default, of which the null stream takes a share - 8 queues give every slot its own (measured: 63.7 -> 49.5 us
+    # per step at 4 slots).  Must be in the environment before the HIP runtime initialises.
+    os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
     import torch
     from gcnn_keras_amd import synth
     from gcnn_keras_amd.engine import SchnetForward
@@ -140,19 +147,25 @@ def main():
     params = synth.schnet_params(seed=7)  # Keras defaults: glorot_uniform kernels, zero biases, U(-0.05, 0.05) embedding
     n_nodes, n_edges, n_graphs = int(batch["node_splits"][-1]), int(batch["edge_splits"][-1]), args.graphs
 
-    fwd = SchnetForward(params, depth=depth, mode=args.mode)
+    fwd = SchnetForward(params, depth=depth, mode=args.mode, in_flight=args.in_flight)
     fwd.load_batch(batch)
-    gathered = torch.empty((world * n_graphs, 1), dtype=torch.float32, device="cuda") if world > 1 else None
+    slots = fwd.in_flight
+    gathered = [torch.empty((world * n_graphs, 1), dtype=torch.float32, device="cuda") for _ in range(slots)] \
+        if world > 1 else None
 
     host_parts = [torch.empty((n_graphs, 1)) for _ in range(world)] if (world > 1 and args.backend == "gloo") else None
 
-    def step():
-        out = fwd.forward()
-        if world > 1:
+    def step(i):
+        # one forward of one batch on its slot's stream; with RCCL the all-gather is ordered after it on that stream
+        # (the process group serialises the collectives of different slots in issue order)
+        if world == 1:
+            return fwd.replay(i)                                       # one C-ABI call: hipGraphLaunch on the slot's stream
+        with torch.cuda.stream(fwd.stream_of(i)):
+            out = fwd.replay(i)
             if host_parts is None:
-                dist.all_gather_into_tensor(gathered, out)       # RCCL, on the forward's stream
+                dist.all_gather_into_tensor(gathered[i % slots], out)
             else:
-                dist.all_gather(host_parts, out.cpu())             # rehearsal only
+                dist.all_gather(host_parts, out.cpu())                 # rehearsal only
         return out
 
     def reduce_scalar(value, op):
@@ -161,17 +174,16 @@ def main():
             dist.all_reduce(t, op=op)
         return float(t.item())
 
-    with torch.cuda.stream(fwd.stream):  # one stream for graph replay and the collective: no cross-stream events
-        for _ in range(args.warmup):
-            step()
-        torch.cuda.synchronize()
-        if world > 1:
-            dist.barrier()
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        for _ in range(args.steps):
-            step()
-        torch.cuda.synchronize()
+    for i in range(args.warmup):
+        step(i)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        step(i)
+    torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
@@ -180,6 +192,16 @@ def main():
     total_edges = reduce_scalar(float(n_edges), dist.ReduceOp.SUM if world > 1 else None)
 
     fwd.check_flags()
+    # latency of ONE forward with nothing else on the GPU (slot 0 alone), for reference beside the throughput
+    with torch.cuda.stream(fwd.stream_of(0)):
+        for _ in range(10):
+            fwd.replay(0)
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        for _ in range(100):
+            fwd.replay(0)
+        torch.cuda.synchronize()
+    latency_ms = (time.perf_counter() - t1) / 100 * 1e3
     roof = fwd.roofline(HBM_PEAK_GBS, FP32_MFMA_PEAK_TF)  # dominant kernel, timed with HIP events on its stream
     roof.update(pmc_traffic(roof.get("kernel", ""), n_graphs))
 
@@ -195,7 +217,11 @@ def main():
             "config": {"workload": "BASELINE config 2: SchNet forward (F=128, depth 3, Gauss 20) on %d QM9-shaped graphs "
                                    "per GPU, N=%d nodes, M=%d directed edges on rank 0" % (n_graphs, n_nodes, n_edges),
                        "graphs_per_gpu": n_graphs, "nodes": n_nodes, "edges": n_edges, "mode": fwd.mode,
+                       "in_flight": slots,
+                       "step": "one forward of one batch; %d independent batch slots (own buffers, HIP stream and "
+                               "graph) are in flight, so kernels of different batches share the GPU" % slots,
                        "sharding": "by graph, 1 all-gather of predictions per step" if world > 1 else "single GPU"},
+            "single_forward_latency_ms": latency_ms,
             "roofline": roof,
             "forward_model": {"hbm_frac": fwd_bytes / (ms_per_step * 1e-3) / (HBM_PEAK_GBS * 1e9),
                               "mfma_frac": fwd_flops / (ms_per_step * 1e-3) / (FP32_MFMA_PEAK_TF * 1e12),

@@ -93,14 +93,17 @@ struct CfconvArgs {
     t_prev = t_now;                                                                    \
   }
 
-template <int WAVES, bool GAUSS, bool FAST_SSP, int NKT, bool DIAG = false>
-__global__ __launch_bounds__(WAVES * 64) void cfconv_fused_kernel(CfconvArgs a) {
+template <int WAVES, bool GAUSS, bool FAST_SSP, int NKT, bool DIAG = false, bool COMPACT = false>
+__global__ __launch_bounds__(WAVES * 64, (WAVES == 4 && COMPACT) ? 2 : 1) void cfconv_fused_kernel(CfconvArgs a) {
   unsigned long long diag_sum[8] = {0, 0, 0, 0, 0, 0, 0, 0};
   unsigned long long t_prev = 0;
   if constexpr (DIAG) t_prev = __builtin_amdgcn_s_memtime();
   extern __shared__ __align__(16) float lds[];
-  float* W1s = lds;                          // [MAX_KROWS][F] packed
-  float* W2s = lds + MAX_KROWS * F;          // [F][F] natural
+  // rows of W1 kept in LDS: all MAX_KROWS in the generic build, the 2 nk that GEMM1 reads when the basis size is fixed
+  // (22 for B = 20: the workgroup then needs 79.3 KB, so two workgroups - e.g. of two forwards in flight - share a CU)
+  constexpr int W1ROWS = NKT > 0 ? 2 * NKT : MAX_KROWS;
+  float* W1s = lds;                          // [W1ROWS][F] packed
+  float* W2s = lds + W1ROWS * F;             // [F][F] natural
   float* Xs = W2s + F * F;                   // [WAVES][2][F] lane-transposition scratch for the boundary atomics
 
   const int tid = threadIdx.x;
@@ -147,7 +150,7 @@ __global__ __launch_bounds__(WAVES * 64) void cfconv_fused_kernel(CfconvArgs a) 
   {
     const float4* src = reinterpret_cast<const float4*>(a.packed);
     float4* dst = reinterpret_cast<float4*>(lds);
-    for (int i = tid; i < (MAX_KROWS * F) / 4; i += WAVES * 64) dst[i] = src[i];
+    for (int i = tid; i < (W1ROWS * F) / 4; i += WAVES * 64) dst[i] = src[i];
   }
   float bias2[4];
 #pragma unroll
@@ -181,8 +184,9 @@ __global__ __launch_bounds__(WAVES * 64) void cfconv_fused_kernel(CfconvArgs a) 
 
     // ---- sender rows of this tile (one 16-B read per lane and edge: a half wave reads one whole 512-B row).  With
     //      one wave per SIMD they are requested first and consumed after GEMM2; with two waves per SIMD (WAVES = 8,
-    //      256 registers per wave) they are requested only after GEMM2 - the sibling wave's MFMAs cover the latency. ----
-    constexpr bool LATE_X = WAVES > 4;
+    //      256 registers per wave) they are requested only after GEMM2 - the sibling wave's MFMAs cover the latency; the
+    //      256-register 4-wave build requests them right before GEMM2. ----
+    constexpr int X_AT = WAVES > 4 ? 2 : (COMPACT ? 1 : 0);  // 0: tile start, 1: before GEMM2, 2: after GEMM2
     float xv[4][16];
     auto load_sender_rows = [&]() {
 #pragma unroll
@@ -197,7 +201,7 @@ __global__ __launch_bounds__(WAVES * 64) void cfconv_fused_kernel(CfconvArgs a) 
         xv[3][r] = t.w;
       }
     };
-    if constexpr (!LATE_X) load_sender_rows();
+    if constexpr (X_AT == 0) load_sender_rows();
     prefetch_tile(tile0 + tile_step);  // next tile's edge data, in flight during this tile's GEMMs
 
     // ---- B operand of GEMM1: this lane's half of its edge's basis row (+ the constant 1 of the bias row) ----
@@ -256,6 +260,7 @@ __global__ __launch_bounds__(WAVES * 64) void cfconv_fused_kernel(CfconvArgs a) 
       __syncthreads();  // drains this wave's LDS-DMA (vmcnt) and publishes all four waves' parts of W2
       w2_ready = true;
     }
+    if constexpr (X_AT == 1) load_sender_rows();
     MP_STAMP(3)
     // ---- GEMM2: w[e][j] = sum_f h[e][f] W2[f][j] + b2[j]; A = the accumulator registers of GEMM1 ------------
     floatx16 w[4];
@@ -278,7 +283,7 @@ __global__ __launch_bounds__(WAVES * 64) void cfconv_fused_kernel(CfconvArgs a) 
     }
 
     MP_STAMP(4)
-    if constexpr (LATE_X) load_sender_rows();
+    if constexpr (X_AT == 2) load_sender_rows();
     // ---- multiply by the sender row and sum the segments IN REGISTERS.  Each lane half holds 16 consecutive edges
     //      (register order) of the lane's four feature columns.  The segment structure is wave-uniform data (one
     //      32-bit start mask from a ballot), so the walk is driven by SCALAR tests: a step without a boundary in either
@@ -415,26 +420,32 @@ __global__ void cfconv_pack_kernel(const float* __restrict__ W1, const float* __
   }
 }
 
-template <int WAVES>
+template <int WAVES, int NKT>
 size_t cfconv_lds_bytes() {
-  return sizeof(float) * (MAX_KROWS * F + F * F + WAVES * 2 * F);
+  return sizeof(float) * ((NKT > 0 ? 2 * NKT : MAX_KROWS) * F + F * F + WAVES * 2 * F);
 }
 
-template <int WAVES, bool GAUSS, bool FAST, int NKT, bool DIAG>
+template <int WAVES, bool GAUSS, bool FAST, int NKT, bool DIAG, bool COMPACT = false>
 int launch_cfconv(const CfconvArgs& args, int grid, hipStream_t s) {
-  const size_t lds = cfconv_lds_bytes<WAVES>();
+  const size_t lds = cfconv_lds_bytes<WAVES, NKT>();
   static bool attr_set = false;
   if (!attr_set) {
-    MP_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&cfconv_fused_kernel<WAVES, GAUSS, FAST, NKT, DIAG>),
-                               hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds)));
+    MP_HIP(hipFuncSetAttribute(
+        reinterpret_cast<const void*>(&cfconv_fused_kernel<WAVES, GAUSS, FAST, NKT, DIAG, COMPACT>),
+        hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds)));
     attr_set = true;
   }
-  cfconv_fused_kernel<WAVES, GAUSS, FAST, NKT, DIAG><<<grid, WAVES * 64, lds, s>>>(args);
+  cfconv_fused_kernel<WAVES, GAUSS, FAST, NKT, DIAG, COMPACT><<<grid, WAVES * 64, lds, s>>>(args);
   return mp::check_launch("mp_cfconv_fused_f32");
 }
 
 template <bool GAUSS, bool FAST>
-int launch_by_basis(const CfconvArgs& args, int waves, int grid, hipStream_t s) {
+int launch_by_basis(const CfconvArgs& args, int waves, int grid, bool compact, hipStream_t s) {
+  if constexpr (GAUSS) {
+    // 256-register build of the 4-wave kernel (sender rows requested before GEMM2 instead of at tile start): two
+    // workgroups fit on a CU, which pays when several forwards are in flight on separate streams.
+    if (waves == 4 && compact && args.B == 20) return launch_cfconv<4, true, FAST, 11, false, true>(args, grid, s);
+  }
   if (waves == 8) {
     if (args.B == 20) return launch_cfconv<8, GAUSS, FAST, 11, false>(args, grid, s);
     return launch_cfconv<8, GAUSS, FAST, 0, false>(args, grid, s);
@@ -457,10 +468,11 @@ int cfconv_dispatch(CfconvArgs args, bool gauss, int flags, hipStream_t s) {
   // segment walk); a second wave per SIMD fills those gaps once the waves run out of step, i.e. when every wave has
   // several tiles: 8 waves (256 registers each, sender rows loaded late) from 4096 tiles on - measured 812 vs 928 us at
   // 2.5 M edges, 87 vs 93 us at 0.2 M - and 4 waves (one tile per wave spread over more CUs) below.  Flag bit 2 forces
-  // 8 waves, bit 3 forces 4.
+  // 8 waves, bit 3 forces 4, bit 4 selects the 256-register 4-wave build (Gauss variant, 20 bins).
   int waves = args.ntiles >= 4096 ? 8 : 4;
   if (flags & 4) waves = 8;
   if (flags & 8) waves = 4;
+  const bool compact = (flags & 16) != 0;
   int grid = (args.ntiles + waves - 1) / waves;
   if (grid > 256) grid = 256;
   if (args.diag) {
@@ -469,9 +481,11 @@ int cfconv_dispatch(CfconvArgs args, bool gauss, int flags, hipStream_t s) {
     return launch_cfconv<4, true, true, 11, true>(args, grid, s);
   }
   if (gauss) {
-    return fast ? launch_by_basis<true, true>(args, waves, grid, s) : launch_by_basis<true, false>(args, waves, grid, s);
+    return fast ? launch_by_basis<true, true>(args, waves, grid, compact, s)
+                : launch_by_basis<true, false>(args, waves, grid, compact, s);
   }
-  return fast ? launch_by_basis<false, true>(args, waves, grid, s) : launch_by_basis<false, false>(args, waves, grid, s);
+  return fast ? launch_by_basis<false, true>(args, waves, grid, compact, s)
+              : launch_by_basis<false, false>(args, waves, grid, compact, s);
 }
 
 }  // namespace

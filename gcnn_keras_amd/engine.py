@@ -44,7 +44,13 @@ class _HipTimer:
 
 
 class SchnetForward:
-    def __init__(self, params, depth=3, mode="auto", units=128, bins=20, gauss_args=None):
+    """``in_flight`` (fused mode): number of independent batch slots, each with its own buffers, HIP stream and captured
+    graph.  A 128-graph batch fills neither the chip (819 edge tiles on 1024 SIMDs, 144 node tiles on 256 CUs) nor a
+    SIMD's matrix pipe (FP32 MFMA and the wave's own vector phases exclude each other), so a serving / training loop
+    that keeps several batches in flight lets the kernels of different batches share CUs: ``forward(i)`` runs slot
+    ``i % in_flight`` on that slot's stream."""
+
+    def __init__(self, params, depth=3, mode="auto", units=128, bins=20, gauss_args=None, in_flight=1):
         from .literature import Schnet
         if not torch.cuda.is_available():
             raise _ffi.EngineError("SchnetForward needs an MI355X (no CPU fallback)")
@@ -60,9 +66,15 @@ class SchnetForward:
         self.model.set_weights(list(params.values()))
         self._batch = None
         self._fused = None
+        self._slots = []
+        self.in_flight = max(1, int(in_flight)) if mode == "fused" else 1
         if mode == "fused":
             from .fused import FusedSchnet
-            self._fused = FusedSchnet(params, depth=depth, gauss_args=self.gauss_args)
+            # several forwards in flight: the 256-register / 79 KB cfconv build lets two workgroups share a CU
+            flags = 16 if self.in_flight > 1 else 0
+            self._slots = [FusedSchnet(params, depth=depth, gauss_args=self.gauss_args, cfconv_flags=flags)
+                           for _ in range(self.in_flight)]
+            self._fused = self._slots[0]
 
     # ------------------------------------------------------------------------------------------------ batch
     def load_batch(self, batch):
@@ -79,8 +91,12 @@ class SchnetForward:
         self.N = int(batch["node_splits"][-1])
         self.M = int(batch["edge_splits"][-1])
         self.G = len(batch["node_splits"]) - 1
-        if self._fused is not None:
-            self._fused.bind(self._batch, self.N, self.M, self.G)
+        for k, slot in enumerate(self._slots):
+            # every slot owns a copy of the inputs, as it would hold a different batch in production
+            own = self._batch if k == 0 else {key: (v.clone() if torch.is_tensor(v) else v)
+                                              for key, v in self._batch.items()}
+            slot.bind(own, self.N, self.M, self.G)
+            slot.forward()  # captures the slot's graph now, outside any timed region
         torch.cuda.synchronize()
 
     def _fresh_inputs(self):
@@ -96,22 +112,33 @@ class SchnetForward:
                 rag(b["idx"], b["es"], b["es_host"])]
 
     # ------------------------------------------------------------------------------------------------ forward
-    def forward(self):
+    def forward(self, step=0):
         if self._fused is not None:
-            return self._fused.forward()
+            return self._slots[step % self.in_flight].forward()
         before = _ffi.launch_count()
         out = self.model(self._fresh_inputs())
         self.num_launches = _ffi.launch_count() - before
         return out
+
+    def replay(self, step=0):
+        """Fused mode: launch slot ``step % in_flight``'s captured forward on its own stream (one C-ABI call, no stream
+        context switching on the host); layers mode: same as ``forward``."""
+        if self._fused is not None:
+            return self._slots[step % self.in_flight].replay()
+        return self.forward(step)
 
     @property
     def stream(self):
         """The HIP stream the forward is replayed on (run the step loop under ``torch.cuda.stream(fwd.stream)``)."""
         return self._fused.stream if self._fused is not None else torch.cuda.current_stream()
 
+    def stream_of(self, step):
+        """Stream of the slot that serves ``step``."""
+        return self._slots[step % self.in_flight].stream if self._slots else torch.cuda.current_stream()
+
     def check_flags(self):
-        if self._fused is not None:
-            self._fused.check_flags()
+        for slot in self._slots:
+            slot.check_flags()
 
     # ------------------------------------------------------------------------------------------------ roofline
     def roofline(self, hbm_peak_gbs, mfma_peak_tf, iters=50):

@@ -130,3 +130,26 @@ def test_fused_schnet_empty_graphs_and_isolated_nodes():
                             ko.R(b["edge_indices"], b["edge_splits"]), depth=3)
     assert out.shape == ref.shape == (6, 1)
     assert _rel_err(out, ref) <= 1e-5
+
+
+def test_forwards_in_flight_are_independent_and_identical():
+    """``SchnetForward(in_flight=k)``: k batch slots (own buffers / stream / graph, 256-register cfconv build) replayed
+    concurrently give, each, the bits of a lone forward of the same build and stay within 1e-5 of the oracle."""
+    from gcnn_keras_amd.engine import SchnetForward
+    b = synth.qm9_like_batch(num_graphs=128, seed=1234)
+    p = synth.schnet_params(seed=7, random_bias=True)
+    multi = SchnetForward(p, depth=3, mode="fused", in_flight=3)
+    multi.load_batch(b)
+    for i in range(30):                      # slots overlap on the GPU
+        multi.replay(i)
+    torch.cuda.synchronize()
+    outs = [multi._slots[k].out.clone() for k in range(3)]
+    assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2])
+    lone = multi.forward(0).clone()
+    torch.cuda.synchronize()
+    assert torch.equal(lone, outs[0])
+    ref = ko.schnet_forward(p, ko.R(b["node_number"], b["node_splits"]), ko.R(b["node_coordinates"], b["node_splits"]),
+                            ko.R(b["edge_indices"], b["edge_splits"]), depth=3)
+    got = outs[0].cpu().numpy()
+    assert np.max(np.abs(got - ref)) <= 1e-5 * np.max(np.abs(ref))
+    multi.check_flags()
