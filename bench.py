@@ -204,6 +204,10 @@ def main():
     latency_ms = (time.perf_counter() - t1) / 100 * 1e3
     roof = fwd.roofline(HBM_PEAK_GBS, FP32_MFMA_PEAK_TF)  # dominant kernel, timed with HIP events on its stream
     roof.update(pmc_traffic(roof.get("kernel", ""), n_graphs))
+    roof["measured"] = ("HIP events on the kernel's stream around back-to-back launches of the kernel alone on the GPU, after "
+                        "the timed region; rocprofv3 of `bench.py --in-flight 1` (profiles/r01_fused_config2_kernel_stats.csv) "
+                        "gives the same average; with batches in flight kernels of different batches share CUs and their "
+                        "individual durations stretch (profiles/r01_fused_config2_inflight4_kernel_stats.csv)")
 
     if rank == 0:
         ms_per_step = elapsed / args.steps * 1e3

@@ -57,7 +57,8 @@ def pmc(fetch_dir, write_dir, label):
 
 os.makedirs(os.path.join(ROOT, "profiles"), exist_ok=True)
 kernel_stats("prof_layers", "%s_layers_mode_kernel_stats.csv" % tag, "bench.py --mode layers (one engine call per Keras layer), config 2")
-kernel_stats("prof_fused4", "%s_fused_config2_kernel_stats.csv" % tag, "bench.py (fused, HIP graph), config 2: 128 graphs")
+kernel_stats("prof_fused4", "%s_fused_config2_kernel_stats.csv" % tag, "bench.py --in-flight 1 (fused, HIP graph, one forward at a time), config 2: 128 graphs")
+kernel_stats("prof_inflight", "%s_fused_config2_inflight4_kernel_stats.csv" % tag, "bench.py (default: 4 batches in flight on 4 streams; kernel durations include time shared with other batches), config 2")
 kernel_stats("prof_big", "%s_fused_12500graphs_kernel_stats.csv" % tag, "bench.py --graphs 12500 (config-4 shard size), fused")
 res = [pmc("pmc_fetch", "pmc_write", "config 2 (128 graphs, N=2301, M=26190)"),
        pmc("pmc_fetch_big", "pmc_write_big", "12500 graphs (N=225225, M=2556724)")]
