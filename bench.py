@@ -115,9 +115,9 @@ def main():
                     help="nccl = RCCL over xGMI (production); gloo only rehearses N > 1 on a single-GPU box")
     args = ap.parse_args()
 
-    # Several forwards are kept in flight on separate HIP streams (--in-flight); ROCm maps streams onto 4 hardware queues
-    # by default, of which the null stream takes a share - 8 queues give every slot its own (measured: 63.7 -> 49.5 us
-    # per step at 4 slots).  Must be in the environment before the HIP runtime initialises.
+    # Several forwards are kept in flight on separate HIP streams (--in-flight).  ROCm multiplexes streams onto a few
+    # hardware queues; 8 instead of the default 4 leave room beside the null stream, and SchnetForward.load_batch picks
+    # the best of a few stream draws (engine.py:_place_streams).  Must be set before the HIP runtime initialises.
     os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
     import torch
     from gcnn_keras_amd import synth

@@ -42,6 +42,6 @@ def run(graphs, k, steps=400, cf=0):
 
 if __name__ == "__main__":
     g = int(sys.argv[1]) if len(sys.argv) > 1 else 128
-    for cf in (16,):
-        for k in (1, 2, 3, 4, 5, 6, 8):
+    for cf in (16, 4, 0):
+        for k in (1, 3, 4):
             run(g, k, cf=cf)
