@@ -293,7 +293,7 @@ __device__ __forceinline__ void schnet_node_body(const NodeArgs& a, int block, i
 }
 
 template <int MODE, int E, int RB, bool FAST>
-__global__ __launch_bounds__(256, (RB == 4 && MODE != NODE_LAST) ? 2 : 1) void schnet_node_kernel(NodeArgs a) {
+__global__ __launch_bounds__(256, MODE != NODE_LAST ? 2 : 1) void schnet_node_kernel(NodeArgs a) {
   schnet_node_body<MODE, E, RB, FAST>(a, blockIdx.x, gridDim.x);
 }
 
