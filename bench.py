@@ -10,6 +10,12 @@ preparation (shift, CSR), geometry, basis expansion, every interaction block, re
 Graphs shard by rank with no data-path collective (weak scaling: every rank owns its own 128-graph batch); the only
 collective is one all-gather of the (G,1) predictions per step (RCCL over xGMI), as BASELINE.json's north_star states.
 
+One 128-graph forward cannot fill an MI355X (819 edge tiles for 1024 SIMDs, 144 node tiles for 256 CUs), so the loop keeps
+`--in-flight` (default 4) independent batch slots - own buffers, own HIP stream, own captured graph - busy: step i is one
+full forward of slot i % 4, launched with one hipGraphLaunch; kernels of different slots overlap on the GPU.  Exactly K
+forwards run inside the timed region.  `single_forward_latency_ms` reports the latency of a lone forward beside the
+throughput; `--in-flight 1` runs strictly one forward at a time.
+
 Prints ONE JSON line (rank 0) with the contract keys plus `roofline` (dominant kernel, measured live with HIP events)
 and `cpu_baseline` (the NumPy oracle restating the reference's unfused TF op sequence, timed on the host cores).
 """
