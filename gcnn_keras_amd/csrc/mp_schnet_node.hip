@@ -7,7 +7,7 @@
 //   readout: PoolingNodes(sum) + MLP([64, 1])            Schnet.py:133-135
 //
 // These chains are latency bound at QM9 batch sizes (2301 nodes = 144 tiles of 16): four waves of a workgroup
-// cooperate on one tile, each wave producing a 32-column slice of every GEMM with v_mfma_f32_16x16x4_f32 (two
+// cooperate on one tile (16 nodes for small N, 32 for large N), each wave producing a 32-column slice of every GEMM with v_mfma_f32_16x16x4_f32 (two
 // independent 16x16 accumulators per wave cover its 40-cycle dependent latency).  The wave keeps its slice of
 // every weight matrix in REGISTERS for the life of the persistent workgroup (64 VGPRs per 128x32 slice, loaded
 // once with coalesced 64-B reads), so the only LDS traffic is the 16x128 activation tile handed from one GEMM to
@@ -353,8 +353,10 @@ __global__ __launch_bounds__(256) void schnet_readout_kernel(const float* __rest
 }
 
 // Small batches (every 16-node tile gets a workgroup of its own on the 256 CUs) are latency bound: 16-node tiles.
-// Large batches are throughput bound: 64-node tiles (each weight register feeds 4 MFMAs, 4x fewer barriers per node)
-// and two workgroups per CU so that one tile's barriers / epilogue hide under the other's MFMAs.
+// Large batches are throughput bound: 32-node tiles (each weight register feeds 2 MFMAs) and two workgroups per CU so
+// that one tile's barriers / epilogue hide under the other's MFMAs.  64-node tiles measured slower (3686 vs 3580 us per
+// forward at 225 k nodes, 452 vs 407 us at 18 k): next to 32 accumulator and 32 staging registers the three resident
+// weight slices no longer fit 256 registers and are reloaded from scratch inside the MFMA loop.
 template <int MODE, int E, bool FAST>
 int launch_node_impl(NodeArgs a, hipStream_t s, const char* what) {
   const int64_t tiles16 = (a.N + 15) / 16;
@@ -363,9 +365,9 @@ int launch_node_impl(NodeArgs a, hipStream_t s, const char* what) {
     const int grid = a.ntiles < 512 ? a.ntiles : 512;
     schnet_node_kernel<MODE, E, 1, FAST><<<grid, 256, 0, s>>>(a);
   } else {
-    a.ntiles = static_cast<int>((a.N + 63) / 64);
+    a.ntiles = static_cast<int>((a.N + 31) / 32);
     const int grid = a.ntiles < 512 ? a.ntiles : 512;
-    schnet_node_kernel<MODE, E, 4, FAST><<<grid, 256, 0, s>>>(a);
+    schnet_node_kernel<MODE, E, 2, FAST><<<grid, 256, 0, s>>>(a);
   }
   return mp::check_launch(what);
 }
