@@ -24,11 +24,13 @@ constexpr int F = 128;
 constexpr int X_LD = 130;  // padded row stride of the LDS activation tiles: (2*node + k) mod 32 is conflict-free
 
 __device__ __forceinline__ float ssp_exact(float x) { return mp_softplus(x) - 0.6931471805599453f; }
-// v_exp_f32 / v_log_f32 form of the shifted softplus (same as csrc/mp_cfconv.hip; |delta| < 2e-7 vs ssp_exact)
+// v_exp_f32 / v_log_f32 form of the shifted softplus in six VALU instructions (same as csrc/mp_cfconv.hip;
+// |delta| < 2e-7 vs ssp_exact): max(x,0) + ln2 * log2((1 + 2^(-|x| log2 e)) / 2), the max as an integer max on the bits.
 __device__ __forceinline__ float ssp_fast(float x) {
   const float t = __builtin_amdgcn_exp2f(fabsf(x) * -1.4426950408889634f);
-  const float l = __builtin_amdgcn_logf(1.0f + t);
-  return fmaf(l - 1.0f, 0.6931471805599453f, fmaxf(x, 0.0f));
+  const float l = __builtin_amdgcn_logf(__builtin_fmaf(t, 0.5f, 0.5f));
+  const int xi = __float_as_int(x);
+  return __builtin_fmaf(l, 0.6931471805599453f, __int_as_float(xi > 0 ? xi : 0));
 }
 template <bool FAST>
 __device__ __forceinline__ float ssp(float x) { return FAST ? ssp_fast(x) : ssp_exact(x); }
