@@ -46,7 +46,8 @@ struct EdgePrepArgs {
 // dependent round trips (search steps -> offsets -> index row -> coordinates), so removing the ~7 search trips is what
 // matters.  Larger batches search the L2-resident arrays directly (one wave-uniform search + a short walk).
 // `block` / `nblocks`: this workgroup's position among the workgroups doing edge preparation.
-template <bool LDS_SPLITS>
+// COL1: also track the sortedness of the sender column (the generic index plan reports both columns).
+template <bool LDS_SPLITS, bool COL1 = false>
 __device__ __forceinline__ void edge_prepare_body(const EdgePrepArgs& p, int64_t block, int64_t nblocks) {
   const int64_t* __restrict__ idx = p.idx;
   const int64_t* __restrict__ node_splits = p.node_splits;
@@ -96,7 +97,15 @@ __device__ __forceinline__ void edge_prepare_body(const EdgePrepArgs& p, int64_t
     p.send[e] = static_cast<int32_t>(sj);
     // receiver of the previous edge: only the same graph can break the order (an earlier graph's ids are smaller
     // because node offsets grow with the graph index)
-    if (g_start < e && idx[(e - 1) * 2] + base > si) local_flags |= MP_FLAG_UNSORTED_COL0;
+    if (g_start < e) {
+      if constexpr (COL1) {
+        const longlong2 pv = reinterpret_cast<const longlong2*>(idx)[e - 1];
+        if (pv.x + base > si) local_flags |= MP_FLAG_UNSORTED_COL0;
+        if (pv.y + base > sj) local_flags |= MP_FLAG_UNSORTED_COL1;
+      } else {
+        if (idx[(e - 1) * 2] + base > si) local_flags |= MP_FLAG_UNSORTED_COL0;
+      }
+    }
     if (p.dist) {
       const float dx = xyz[si * 3 + 0] - xyz[sj * 3 + 0];
       const float dy = xyz[si * 3 + 1] - xyz[sj * 3 + 1];

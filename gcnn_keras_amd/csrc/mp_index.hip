@@ -92,9 +92,9 @@ __global__ void csr_from_sorted_kernel(const int32_t* __restrict__ seg, int64_t 
 // index_prepare (K = 2) fused with the geometry pre-step NodePosition -> LazySubtract -> EuclideanNorm
 // (kgcnn/literature/Schnet.py:116-117): one pass over the (M,2) int64 rows yields receiver / sender ids and the
 // edge distance the Gauss expansion starts from.
-template <bool LDS_SPLITS>
+template <bool LDS_SPLITS, bool COL1 = false>
 __global__ __launch_bounds__(256) void edge_prepare_kernel(mp_prep::EdgePrepArgs p) {
-  mp_prep::edge_prepare_body<LDS_SPLITS>(p, blockIdx.x, gridDim.x);
+  mp_prep::edge_prepare_body<LDS_SPLITS, COL1>(p, blockIdx.x, gridDim.x);
 }
 
 __global__ void iota_kernel(int32_t* __restrict__ out, int64_t n) {
@@ -128,6 +128,17 @@ int mp_index_prepare_i64(const int64_t* idx, int64_t M, int K, const int64_t* no
   MP_REQUIRE(flags != nullptr, "mp_index_prepare_i64: null flags");
   if (M == 0) return MP_OK;
   MP_REQUIRE(idx && cols && node_splits && edge_splits && G > 0, "mp_index_prepare_i64: null pointer / no graphs");
+  if (K == 2) {
+    // (receiver, sender) pairs - every conv of the reference: one 16-B load per edge, row_splits searched in LDS for
+    // batches up to 1023 graphs (the edge-preparation body of the fused forward, with both sortedness flags)
+    mp_prep::EdgePrepArgs p{idx, M, node_splits, edge_splits, G, N, nullptr, cols, cols + M, nullptr, flags};
+    if (G <= mp_prep::PREP_LDS_GRAPHS) {
+      edge_prepare_kernel<true, true><<<mp::grid_for(M), 256, 0, mp::as_stream(stream)>>>(p);
+    } else {
+      edge_prepare_kernel<false, true><<<mp::grid_for(M), 256, 0, mp::as_stream(stream)>>>(p);
+    }
+    return mp::check_launch("mp_index_prepare_i64");
+  }
   index_prepare_kernel<<<mp::grid_for(M), 256, 0, mp::as_stream(stream)>>>(idx, M, K, node_splits, edge_splits, G, N,
                                                                             cols, flags);
   return mp::check_launch("mp_index_prepare_i64");

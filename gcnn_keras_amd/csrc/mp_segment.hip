@@ -55,12 +55,13 @@ __global__ void segment_reduce_csr_kernel(int op, const float* __restrict__ data
     for (int i = 0; i < W; ++i) acc[i] = 0.0f;
     float wsum = 0.0f;
     const float* base = data + c * W;
-    // rows are fetched four at a time (independent loads in flight), then folded in edge order
-    for (int64_t e0 = a; e0 < b; e0 += 4) {
-      float v[4][W];
-      float wv[4];
+    constexpr int UB = 8;
+    // rows are fetched UB (eight) at a time (independent loads in flight), then folded in edge order
+    for (int64_t e0 = a; e0 < b; e0 += UB) {
+      float v[UB][W];
+      float wv[UB];
 #pragma unroll
-      for (int u = 0; u < 4; ++u) {
+      for (int u = 0; u < UB; ++u) {
         wv[u] = 1.0f;
         if (e0 + u < b) {
           const int64_t r = perm ? static_cast<int64_t>(perm[e0 + u]) : (e0 + u);
@@ -75,7 +76,7 @@ __global__ void segment_reduce_csr_kernel(int op, const float* __restrict__ data
         }
       }
 #pragma unroll
-      for (int u = 0; u < 4; ++u) {
+      for (int u = 0; u < UB; ++u) {
         if (e0 + u < b) {
           if (weight) {
             wsum += wv[u];

@@ -39,7 +39,11 @@ def main():
         rows.append((name, ms * 1e3, nbytes / 1e6, gbs, gbs / HBM))
 
     g_out, g_cat, pool, pooln = GatherNodesOutgoing(), GatherNodes(), PoolingLocalEdges("sum"), PoolingNodes("sum")
-    bench("index plan (mp_index_prepare_i64)", lambda: RaggedTensor(idx.values, idx.row_splits).index_plan(nodes),
+    cols_buf = torch.empty((2, m), dtype=torch.int32, device="cuda")
+    flag_buf = torch.zeros(1, dtype=torch.int32, device="cuda")
+    bench("index plan (mp_index_prepare_i64)",
+          lambda: _ffi.call("mp_index_prepare_i64", _ffi.ptr(idx.values), m, 2, _ffi.ptr(nodes.row_splits),
+                            _ffi.ptr(idx.row_splits), graphs, n, _ffi.ptr(cols_buf), _ffi.ptr(flag_buf), _ffi.stream()),
           16 * m + 8 * m)
     bench("GatherNodesOutgoing", lambda: g_out([nodes, idx]), 8 * m + 4 * n * f + 4 * m * f)
     bench("GatherNodes (concat i||j)", lambda: g_cat([nodes, idx]), 16 * m + 4 * n * f + 8 * m * f)
