@@ -166,12 +166,12 @@ def main():
         # (the process group serialises the collectives of different slots in issue order)
         if world == 1:
             return fwd.replay(i)                                       # one C-ABI call: hipGraphLaunch on the slot's stream
-        with torch.cuda.stream(fwd.stream_of(i)):
-            out = fwd.replay(i)
-            if host_parts is None:
-                dist.all_gather_into_tensor(gathered[i % slots], out)
-            else:
-                dist.all_gather(host_parts, out.cpu())                 # rehearsal only
+        torch.cuda.set_stream(fwd.stream_of(i))                        # cheaper than a stream context per step
+        out = fwd.replay(i)
+        if host_parts is None:
+            dist.all_gather_into_tensor(gathered[i % slots], out)
+        else:
+            dist.all_gather(host_parts, out.cpu())                     # rehearsal only
         return out
 
     def reduce_scalar(value, op):
@@ -189,6 +189,7 @@ def main():
     t0 = time.perf_counter()
     for i in range(args.steps):
         step(i)
+    torch.cuda.set_stream(torch.cuda.default_stream())
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()

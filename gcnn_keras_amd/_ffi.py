@@ -20,7 +20,7 @@ MP_FLAG_OOB, MP_FLAG_UNSORTED_COL0, MP_FLAG_UNSORTED_COL1 = 1, 2, 4
 
 ACTIVATION_CODES = {
     None: 0, "linear": 0, "relu": 1, "kgcnn>shifted_softplus": 2, "shifted_softplus": 2, "softplus": 3,
-    "swish": 4, "sigmoid": 5, "tanh": 6, "kgcnn>leaky_relu": 7, "leaky_relu": 7,
+    "swish": 4, "sigmoid": 5, "tanh": 6, "kgcnn>leaky_relu": 7, "leaky_relu": 7, "kgcnn>softplus2": 8, "softplus2": 8,
 }
 
 P = c_void_p

@@ -13,6 +13,7 @@ __device__ __forceinline__ float act_grad(int act, float alpha, float x) {
   switch (act) {
     case MP_ACT_RELU: return x > 0.0f ? 1.0f : 0.0f;
     case MP_ACT_SHIFTED_SOFTPLUS:
+    case MP_ACT_SOFTPLUS2:
     case MP_ACT_SOFTPLUS: return sigmoidf_(x);
     case MP_ACT_SWISH: { const float s = sigmoidf_(x); return s + x * s * (1.0f - s); }
     case MP_ACT_SIGMOID: { const float s = sigmoidf_(x); return s * (1.0f - s); }
@@ -133,7 +134,7 @@ extern "C" {
 
 int mp_activation_grad_f32(int act, float act_alpha, const float* pre, const float* gy, int64_t n, float* out,
                            mpStream_t stream) {
-  MP_REQUIRE(n >= 0 && act >= MP_ACT_LINEAR && act <= MP_ACT_LEAKY_RELU, "mp_activation_grad_f32: bad arguments");
+  MP_REQUIRE(n >= 0 && act >= MP_ACT_LINEAR && act <= MP_ACT_SOFTPLUS2, "mp_activation_grad_f32: bad arguments");
   if (n == 0) return MP_OK;
   MP_REQUIRE(pre && gy && out, "mp_activation_grad_f32: null pointer");
   activation_grad_kernel<<<mp::grid_for(n), 256, 0, mp::as_stream(stream)>>>(act, act_alpha, pre, gy, n, out);

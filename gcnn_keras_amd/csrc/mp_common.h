@@ -71,6 +71,7 @@ __device__ __forceinline__ float mp_apply_act(int act, float alpha, float v) {
     case MP_ACT_SIGMOID: return 1.0f / (1.0f + expf(-v));
     case MP_ACT_TANH: return tanhf(v);
     case MP_ACT_LEAKY_RELU: return v >= 0.0f ? v : alpha * v;
+    case MP_ACT_SOFTPLUS2: return fmaxf(v, 0.0f) + logf(0.5f * expf(-fabsf(v)) + 0.5f);
     default: return v;
   }
 }

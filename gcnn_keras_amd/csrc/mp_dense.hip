@@ -115,7 +115,7 @@ int mp_dense_f32(const float* x, int64_t R, int64_t K, const float* W, const flo
                  float act_alpha, float* out, mpStream_t stream) {
   MP_REQUIRE(R >= 0 && K >= 1 && U >= 1, "mp_dense_f32: bad sizes R=%lld K=%lld U=%lld", (long long)R, (long long)K,
              (long long)U);
-  MP_REQUIRE(act >= MP_ACT_LINEAR && act <= MP_ACT_LEAKY_RELU, "mp_dense_f32: unknown activation %d", act);
+  MP_REQUIRE(act >= MP_ACT_LINEAR && act <= MP_ACT_SOFTPLUS2, "mp_dense_f32: unknown activation %d", act);
   if (R == 0) return MP_OK;
   MP_REQUIRE(x && W && out, "mp_dense_f32: null pointer");
   const int64_t gy = mp::ceil_div(R, BM), gx = mp::ceil_div(U, BN);
@@ -127,7 +127,7 @@ int mp_dense_f32(const float* x, int64_t R, int64_t K, const float* W, const flo
 
 int mp_activation_f32(int act, float act_alpha, const float* x, int64_t n, float* out, mpStream_t stream) {
   MP_REQUIRE(n >= 0, "mp_activation_f32: bad size");
-  MP_REQUIRE(act >= MP_ACT_LINEAR && act <= MP_ACT_LEAKY_RELU, "mp_activation_f32: unknown activation %d", act);
+  MP_REQUIRE(act >= MP_ACT_LINEAR && act <= MP_ACT_SOFTPLUS2, "mp_activation_f32: unknown activation %d", act);
   if (n == 0) return MP_OK;
   MP_REQUIRE(x && out, "mp_activation_f32: null pointer");
   activation_kernel<<<mp::grid_for(n), 256, 0, mp::as_stream(stream)>>>(act, act_alpha, x, n, out);

@@ -40,7 +40,8 @@ enum mp_reduce_op { MP_SUM = 0, MP_MEAN = 1, MP_MAX = 2, MP_MIN = 3 };
 /* Activations reachable from SchNet / PaiNN / GCN configs (kgcnn/ops/activ.py:6-15, Keras strings) */
 enum mp_activation {
   MP_ACT_LINEAR = 0, MP_ACT_RELU = 1, MP_ACT_SHIFTED_SOFTPLUS = 2, MP_ACT_SOFTPLUS = 3, MP_ACT_SWISH = 4,
-  MP_ACT_SIGMOID = 5, MP_ACT_TANH = 6, MP_ACT_LEAKY_RELU = 7
+  MP_ACT_SIGMOID = 5, MP_ACT_TANH = 6, MP_ACT_LEAKY_RELU = 7,
+  MP_ACT_SOFTPLUS2 = 8 /* kgcnn/ops/activ.py:19-29: relu(x) + log(0.5 exp(-|x|) + 0.5) */
 };
 
 enum mp_binary_op { MP_ADD = 0, MP_SUB = 1, MP_MUL = 2 };

@@ -278,6 +278,13 @@ def leaky_relu(x, alpha=0.05):
     return np.where(x >= 0, x, x.dtype.type(alpha) * x).astype(x.dtype)
 
 
+def softplus2(x):
+    """kgcnn/ops/activ.py:19-29: ``relu(x) + log(0.5 * exp(-|x|) + 0.5)``."""
+    x = np.asarray(x)
+    half = np.asarray(0.5, x.dtype)
+    return (np.maximum(x, 0) + np.log(half * np.exp(-np.abs(x)) + half)).astype(x.dtype)
+
+
 ACTIVATIONS = {
     None: lambda x: x,
     "linear": lambda x: x,
@@ -290,6 +297,8 @@ ACTIVATIONS = {
     "tanh": np.tanh,
     "softmax": softmax_last,
     "kgcnn>leaky_relu": leaky_relu,
+    "kgcnn>softplus2": softplus2,
+    "softplus2": softplus2,
 }
 
 
@@ -872,6 +881,25 @@ def dmpnn_pooling_edges_directed(nodes, edges, idx, reverse_pair):
     ed_new = gather_nodes_outgoing(pool_edge_receive, idx)
     ed_not = dmpnn_gather_edges_pairs(edges, reverse_pair)
     return R(ed_new.values - ed_not.values, ed_new.row_splits)
+
+
+def megnet_block(node, edge, idx, env, p, act="kgcnn>softplus2", pooling_method="mean"):
+    """``MEGnetBlock.call``, kgcnn/layers/conv/megnet_conv.py:96-120.  ``env`` is a dense ``(G, Fu)`` array; ``p`` holds
+    phi_e{,_1,_2}/phi_n{,_1,_2}/phi_u{,_1,_2} kernels and biases.  Returns ``(nodes, edges, env)``."""
+    def chain(x, name):
+        for k, a in (("", act), ("_1", act), ("_2", "linear")):
+            x = dense_values(x, p["%s%s/kernel" % (name, k)], p.get("%s%s/bias" % (name, k)), a)
+        return x
+    e_n = gather_nodes(node, idx)
+    e_u = gather_state(env, edge)
+    ep = R(chain(np.concatenate([e_n.values, edge.values, e_u.values], axis=-1), "phi_e"), edge.row_splits)
+    vb = pooling_local_edges(node, ep, idx, pooling_method=pooling_method)
+    v_u = gather_state(env, node)
+    vp = R(chain(np.concatenate([vb.values, node.values, v_u.values], axis=-1), "phi_n"), node.row_splits)
+    es = pooling_nodes(ep, pooling_method=pooling_method)
+    vs = pooling_nodes(vp, pooling_method=pooling_method)
+    up = chain(np.concatenate([es, vs, env], axis=-1), "phi_u")
+    return vp, ep, up
 
 
 # ----------------------------------------------------------------------------------------

@@ -172,3 +172,46 @@ def test_dmpnn_reference_case():
     result = DMPNNGatherEdgesPairs()([RaggedTensor.from_nested(e1, np.float32, (2,)),
                                       RaggedTensor.from_nested(pairs, np.int64, (1,))])
     assert np.amax(np.abs(result[0].cpu().numpy() - np.array([[1.0, 1.0], [0.0, 0.0], [3.0, 3.0], [2.0, 2.0]]))) < 1e-4
+
+
+def test_softplus2_activation_and_megnet_block():
+    # kgcnn>softplus2 (kgcnn/ops/activ.py:19-29) as a Dense epilogue, then MEGnetBlock (megnet_conv.py:96-120), the one
+    # block that exercises GatherState and the per-graph pools inside a conv
+    from gcnn_keras_amd.layers.conv.megnet_conv import MEGnetBlock
+    from gcnn_keras_amd.layers.modules import Activation
+    x = np.linspace(-30, 30, 601, dtype=np.float32).reshape(-1, 1)
+    from gcnn_keras_amd.ragged import RaggedTensor
+    act = Activation("kgcnn>softplus2")(RaggedTensor.from_numpy(x, np.array([0, len(x)]))).values.cpu().numpy()
+    _close(act, ko.softplus2(x), tol=2e-6)
+    assert abs(float(ko.softplus2(np.zeros(1, np.float32))[0])) == 0.0          # zero at zero by construction
+
+    b = _batch(num_graphs=7, seed=21, f=24, fe=12)
+    rng = np.random.default_rng(9)
+    fu = 10
+    env = rng.normal(size=(7, fu)).astype(np.float32)
+    widths = {"phi_e": (2 * 24 + 12 + fu, [16, 16, 20]), "phi_n": (20 + 24 + fu, [16, 16, 18]),
+              "phi_u": (20 + 18 + fu, [16, 16, 14])}
+    p = {}
+    for name, (fin, outs) in widths.items():
+        for suffix, fout in zip(("", "_1", "_2"), outs):
+            p["%s%s/kernel" % (name, suffix)] = synth.glorot_uniform(rng, fin, fout)
+            p["%s%s/bias" % (name, suffix)] = (rng.normal(size=fout) * 0.1).astype(np.float32)
+            fin = fout
+    block = MEGnetBlock(node_embed=[16, 16, 18], edge_embed=[16, 16, 20], env_embed=[16, 16, 14])
+    inputs = [_dev(b["x"], b["node_splits"]), _dev(b["e"], b["edge_splits"]),
+              _dev(b["edge_indices"], b["edge_splits"]), torch.from_numpy(env).cuda()]
+    block(inputs)   # build
+    assert tuple(block.weights[0][1].shape) == (20 + 24 + fu, 16)                # node chain first, as in the reference
+    weights = []
+    for name in ("phi_n", "phi_e", "phi_u"):
+        for suffix in ("", "_1", "_2"):
+            weights += [p["%s%s/kernel" % (name, suffix)], p["%s%s/bias" % (name, suffix)]]
+    block.set_weights(weights)
+    vp, ep, up = block(inputs)
+    rv, re_, ru = ko.megnet_block(ko.R(b["x"], b["node_splits"]), ko.R(b["e"], b["edge_splits"]),
+                                  ko.R(b["edge_indices"], b["edge_splits"]), env, p)
+    _close(vp.values.cpu().numpy(), rv.values, tol=2e-5)
+    _close(ep.values.cpu().numpy(), re_.values, tol=2e-5)
+    _close(up.cpu().numpy(), ru, tol=2e-5)
+    cfg = block.get_config()
+    assert cfg["activation"] == "kgcnn>softplus2" and cfg["pooling_method"] == "mean" and cfg["env_embed"] == [16, 16, 14]
