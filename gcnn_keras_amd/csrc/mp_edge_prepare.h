@@ -113,7 +113,7 @@ __device__ __forceinline__ void edge_prepare_body(const EdgePrepArgs& p, int64_t
       p.dist[e] = sqrtf(fmaxf(dx * dx + dy * dy + dz * dz, 0.0f));
     }
   }
-  if (local_flags) atomicOr(p.flags, local_flags);
+  mp_publish_flags(p.flags, local_flags);
 }
 
 }  // namespace mp_prep

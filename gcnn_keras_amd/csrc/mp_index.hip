@@ -72,7 +72,7 @@ __global__ void index_prepare_kernel(const int64_t* __restrict__ idx, int64_t M,
       }
     }
   }
-  if (local_flags) atomicOr(flags, local_flags);
+  mp_publish_flags(flags, local_flags);
 }
 
 // ptr[n] = first position e with seg[e] >= n; seg sorted ascending.  ptr is pre-zeroed so that a caller who
