@@ -169,10 +169,8 @@ class MolDynamicsModelPredictor:
         """Seconds per call (kgcnn/moldyn/base.py:167-180)."""
         self(graph_list)
         torch.cuda.synchronize()
-        start = time.process_time()
         wall = time.perf_counter()
         for _ in range(repetitions):
             self(graph_list)
         torch.cuda.synchronize()
-        del start
         return (time.perf_counter() - wall) / repetitions

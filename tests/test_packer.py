@@ -133,3 +133,28 @@ def test_batch_packer_host_half_follows_memory_graph_list_items():
     assert np.array_equal(host["edge_indices"][1], b["edge_splits"])
     assert host["graph_labels"].shape == (7, 1) and host["graph_labels"].dtype == np.float32
     assert host["__plan__"]["N"] == len(b["node_number"])
+
+
+def test_memory_graph_list_and_output_translation_host_side():
+    # list behaviour of the reference container (kgcnn/data/base.py:28-150) and the predictor's output mapping
+    # (kgcnn/moldyn/base.py:81-104); nothing here touches the device
+    from gcnn_keras_amd.data.base import GraphDict, MemoryGraphList
+    from gcnn_keras_amd.moldyn import MolDynamicsModelPredictor
+    gl = MemoryGraphList([{"node_number": np.array([1, 6]), "energy": np.array([0.5])}, {"node_number": np.array([8])}])
+    assert len(gl) == 2 and isinstance(gl[0], GraphDict)
+    assert [None if v is None else v.tolist() for v in gl.obtain_property("energy")] == [[0.5], None]
+    cp = gl.copy()
+    cp[0].set("energy", [2.0])
+    assert gl[0]["energy"][0] == 0.5 and cp[0]["energy"][0] == 2.0
+    gl[1].apply_preprocessor(lambda g: {"charge": np.array([len(g["node_number"])])})
+    assert gl[1]["charge"].tolist() == [1]
+    with pytest.raises(TypeError):
+        gl[1].apply_preprocessor("set_range")      # serialized names are not resolved on this engine
+    tr = MolDynamicsModelPredictor._translate_properties
+    assert tr([1, 2], ["energy", "forces"]) == {"energy": 1, "forces": 2}
+    assert tr({"e": 1, "f": 2}, {"energy": "e", "forces": "f"}) == {"energy": 1, "forces": 2}
+    assert tr(3.0, "energy") == {"energy": 3.0}
+    with pytest.raises(TypeError):
+        tr(3.0, 7)
+    with pytest.raises(TypeError):
+        MolDynamicsModelPredictor(model=None, graph_preprocessors=[{"class_name": "SetRange"}])
