@@ -36,7 +36,7 @@ def _cfconv_case(seed, num_graphs=9, shuffle=False):
 
 @pytest.mark.parametrize("shuffle", [False, True])
 @pytest.mark.parametrize("variant", ["rbf", "gauss"])
-@pytest.mark.parametrize("fast", [0, 1, 4, 5])   # bit0: fast softplus, bit2: force the 8-wave workgroup variant
+@pytest.mark.parametrize("fast", [0, 1, 4, 5, 17])   # bit0: fast softplus, bit2: 8-wave workgroup, bit4: 256-register build
 def test_cfconv_fused_vs_oracle(shuffle, variant, fast):
     from gcnn_keras_amd import _ffi
     from gcnn_keras_amd.ragged import RaggedTensor
@@ -68,6 +68,42 @@ def test_cfconv_fused_vs_oracle(shuffle, variant, fast):
     got = out.cpu().numpy()
     assert _rel_err(got, ref) <= 1e-5                       # north_star tolerance for the float segment-sum
     assert _rel_err(got, ref64) <= max(4 * _rel_err(ref, ref64), 2e-6)
+
+
+@pytest.mark.parametrize("flags", [1, 5, 17])
+def test_cfconv_high_in_degree_segments_span_many_tiles(flags):
+    """Receivers with more than 32 incoming edges: a segment then covers whole 32-edge tiles and is assembled from three
+    or more float atomics (the order of which is not fixed) - still within the 1e-5 bar.  Also exercises a partial last
+    tile, a receiver range that starts mid-tile and nodes without edges."""
+    from gcnn_keras_amd import _ffi
+    rng = np.random.default_rng(4)
+    n = 40
+    degrees = {0: 1, 3: 100, 4: 33, 9: 64, 17: 7, 39: 70}          # receiver -> in-degree; everything else isolated
+    recv = np.concatenate([np.full(d, r) for r, d in sorted(degrees.items())])
+    send = rng.integers(0, n, size=len(recv))
+    idx = np.stack([recv, send], axis=1).astype(np.int64)
+    m = len(idx)
+    ns, es = np.array([0, n], dtype=np.int64), np.array([0, m], dtype=np.int64)
+    x = ko.R(rng.normal(size=(n, 128)).astype(np.float32), ns)
+    dist = ko.R(rng.uniform(0.5, 4.0, size=(m, 1)).astype(np.float32), es)
+    rbf = ko.gauss_basis(dist, 20, 4.0, 0.4)
+    p = {"dense1/kernel": synth.glorot_uniform(rng, 20, 128), "dense1/bias": rng.uniform(-.1, .1, 128).astype(np.float32),
+         "dense2/kernel": synth.glorot_uniform(rng, 128, 128),
+         "dense2/bias": rng.uniform(-.1, .1, 128).astype(np.float32)}
+    ref = ko.schnet_cfconv(x, rbf, ko.R(idx, es), p).values
+    w = {k: torch.from_numpy(v).cuda() for k, v in p.items()}
+    packed = torch.empty(_ffi.lib().mp_cfconv_packed_floats(), dtype=torch.float32, device="cuda")
+    _ffi.call("mp_cfconv_pack_f32", _ffi.ptr(w["dense1/kernel"]), _ffi.ptr(w["dense1/bias"]), 20,
+              _ffi.ptr(w["dense2/kernel"]), _ffi.ptr(w["dense2/bias"]), _ffi.ptr(packed), _ffi.stream())
+    out = torch.zeros((n, 128), dtype=torch.float32, device="cuda")
+    dx, dd = torch.from_numpy(x.values).cuda(), torch.from_numpy(dist.values.reshape(-1)).cuda()
+    dr, dsnd = torch.from_numpy(recv.astype(np.int32)).cuda(), torch.from_numpy(send.astype(np.int32)).cuda()
+    _ffi.call("mp_cfconv_gauss_fused_f32", _ffi.ptr(dx), n, _ffi.ptr(dd), 20, 4.0, 0.4, 0.0, _ffi.ptr(packed),
+              _ffi.ptr(dr), _ffi.ptr(dsnd), None, m, flags, _ffi.ptr(out), _ffi.stream())
+    got = out.cpu().numpy()
+    assert _rel_err(got, ref) <= 1e-5
+    isolated = [r for r in range(n) if r not in degrees]
+    assert np.all(got[isolated] == 0.0)                       # has_unconnected pad, kgcnn/layers/pooling.py:74-76
 
 
 def test_cfconv_no_bias_and_argument_checks():
