@@ -221,10 +221,13 @@ __device__ __forceinline__ void schnet_node_body(const NodeArgs& a, int block, i
 
     if constexpr (EARLY_STAGE) stage_load(tile + nblocks);  // next tile, in flight during the GEMMs
     floatx4 acc[RB][2];
-    // residual rows of n, requested now so that the round trip hides under GEMM 1 and 2
-    constexpr bool PREFETCH_N = RB == 1;  // the 64-node build spends its registers on two workgroups per CU instead
-    float n_res[PREFETCH_N ? RB : 1][2][4];
-    if constexpr (MODE != NODE_IN && PREFETCH_N) {
+    // residual rows of n: requested well before the epilogue that adds them - never inside it, where every load would
+    // have to wait behind the previous element's store to the same array (measured at 225 k nodes: 24 k of a tile's 48 k
+    // cycles).  The 16-node build asks at tile start (hidden under GEMM 1 and 2), the larger tiles right before GEMM 2
+    // so that the values are not live during GEMM 1.
+    constexpr bool N_EARLY = RB == 1;
+    float n_res[RB][2][4];
+    if constexpr (MODE != NODE_IN && N_EARLY) {
       MP_FOR_OUT(cb, r, row, col, {
         n_res[rb][cb][r] = (node0 + row < a.N) ? a.n[(node0 + row) * F + col] : 0.0f;
       })
@@ -247,6 +250,11 @@ __device__ __forceinline__ void schnet_node_body(const NodeArgs& a, int block, i
 
     // ---- GEMM 2: IN: x = n @ Wx ; MID/LAST: n += t @ W3 + b3 ----------------------------------------------------
     MP_ZERO_ACC
+    if constexpr (MODE != NODE_IN && !N_EARLY) {
+      MP_FOR_OUT(cb, r, row, col, {
+        n_res[rb][cb][r] = (node0 + row < a.N) ? a.n[(node0 + row) * F + col] : 0.0f;
+      })
+    }
     gemm_tile<F, 2, RB>(Xb, lane, w_second, acc);
     if constexpr (MODE == NODE_IN) {
       MP_FOR_OUT(cb, r, row, col, {
@@ -256,10 +264,7 @@ __device__ __forceinline__ void schnet_node_body(const NodeArgs& a, int block, i
       MP_FOR_OUT(cb, r, row, col, {
         const bool ok = node0 + row < a.N;
         const float y = acc[rb][cb][r] + bias_second[cb];
-        float nv;
-        if constexpr (PREFETCH_N) nv = n_res[rb][cb][r];
-        else nv = ok ? a.n[(node0 + row) * F + col] : 0.0f;
-        const float nn = nv + y;  // LazyAdd([node, x])
+        const float nn = n_res[rb][cb][r] + y;  // LazyAdd([node, x])
         if (ok && MODE == NODE_MID) a.n[(node0 + row) * F + col] = nn;
         Xa[row * X_LD + col] = nn;
       })

@@ -1,0 +1,28 @@
+"""Phase breakdown of the SchNet node-update kernel (diagnostic build only: MP_LIB=.../lib_diag.so)."""
+import sys, os, ctypes
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np, torch
+from gcnn_keras_amd import _ffi, synth
+_ffi.LIB_PATH = os.path.abspath(os.environ["MP_LIB"])
+from gcnn_keras_amd.engine import _HipTimer
+
+graphs = int(sys.argv[1]) if len(sys.argv) > 1 else 12500
+b = synth.qm9_like_batch(num_graphs=graphs, seed=1234)
+n = int(b["node_splits"][-1])
+p = synth.schnet_params(seed=7)
+dev = lambda a: torch.from_numpy(np.ascontiguousarray(a)).cuda()
+agg = torch.randn(n, 128, device="cuda"); nn_ = torch.randn(n, 128, device="cuda"); x = torch.empty(n, 128, device="cuda")
+W2, b2 = dev(p["interaction0/dense2/kernel"]), dev(p["interaction0/dense2/bias"])
+W3, b3 = dev(p["interaction0/dense3/kernel"]), dev(p["interaction0/dense3/bias"])
+Wx = dev(p["interaction1/dense1/kernel"])
+def launch():
+    _ffi.call("mp_schnet_node_update_f32", _ffi.ptr(agg), n, _ffi.ptr(W2), _ffi.ptr(b2), _ffi.ptr(W3), _ffi.ptr(b3),
+              _ffi.ptr(nn_), _ffi.ptr(Wx), _ffi.ptr(x), 1, _ffi.stream())
+ms = _HipTimer().time_ms(launch, 10)
+lib = _ffi.lib(); out = (ctypes.c_ulonglong * 8)()
+lib.mp_debug_node_diag(out); launch(); torch.cuda.synchronize(); lib.mp_debug_node_diag(out)
+v = np.array(list(out), dtype=np.float64)
+names = ["stage+barrier", "gemm1", "epi1+barrier", "gemm2", "epi2+barrier", "gemm3", "epi3+barrier", "loop"]
+tiles = (n + 31) // 32 if n > 16384 else (n + 15) // 16
+print("N=%d node MID %.1f us; cycles per tile (thread 0 of each workgroup):" % (n, ms * 1e3))
+print("  " + "  ".join("%s %.0f" % (nm, x_ / tiles) for nm, x_ in zip(names, v)), " total %.0f" % (v.sum() / tiles))
