@@ -16,6 +16,23 @@
 #include "mp_common.h"
 #include "mp_edge_prepare.h"
 
+// Diagnostic build (make diag -> libmpengine_diag.so, scripts/probe_node_diag.py): cycle stamps around the phases of the
+// node-update tile loop.  Compiles to nothing in the product library.
+#ifdef MP_NODE_DIAG
+__device__ unsigned long long g_node_diag[8];
+#define MP_NSTAMP(i)                                                      \
+  {                                                                       \
+    __builtin_amdgcn_sched_barrier(0);                                    \
+    const unsigned long long t_now = __builtin_amdgcn_s_memtime();        \
+    __builtin_amdgcn_s_waitcnt(0xC07F);                                   \
+    __builtin_amdgcn_sched_barrier(0);                                    \
+    dsum[i] += t_now - t_prev;                                            \
+    t_prev = t_now;                                                       \
+  }
+#else
+#define MP_NSTAMP(i)
+#endif
+
 namespace {
 
 using floatx4 = __attribute__((ext_vector_type(4))) float;
@@ -207,8 +224,13 @@ __device__ __forceinline__ void schnet_node_body(const NodeArgs& a, int block, i
   }
   bias_fourth = (MODE == NODE_LAST && a.bl1) ? a.bl1[wave * 16 + (lane & 15)] : 0.0f;
 
+#ifdef MP_NODE_DIAG
+  unsigned long long dsum[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  unsigned long long t_prev = __builtin_amdgcn_s_memtime();
+#endif
   for (int tile = block; tile < a.ntiles; tile += nblocks) {
     const int64_t node0 = static_cast<int64_t>(tile) * TN;
+    MP_NSTAMP(7)
 
     // ---- stage the input tile into Xa (coalesced; the consumed aggregation rows were re-zeroed by stage_load) --------
     if constexpr (EARLY_STAGE) {
@@ -218,6 +240,7 @@ __device__ __forceinline__ void schnet_node_body(const NodeArgs& a, int block, i
       stage_store();
     }
     __syncthreads();
+    MP_NSTAMP(0)
 
     if constexpr (EARLY_STAGE) stage_load(tile + nblocks);  // next tile, in flight during the GEMMs
     floatx4 acc[RB][2];
@@ -238,6 +261,7 @@ __device__ __forceinline__ void schnet_node_body(const NodeArgs& a, int block, i
       _Pragma("unroll") for (int cb = 0; cb < 2; ++cb) acc[rb][cb] = floatx4{0.f, 0.f, 0.f, 0.f};
     MP_ZERO_ACC
     gemm_tile<(MODE == NODE_IN ? E : F), 2, RB>(Xa, lane, w_first, acc);
+    MP_NSTAMP(1)
     MP_FOR_OUT(cb, r, row, col, {
       float v = acc[rb][cb][r] + bias_first[cb];
       if constexpr (MODE != NODE_IN) v = ssp<FAST>(v);
@@ -247,6 +271,7 @@ __device__ __forceinline__ void schnet_node_body(const NodeArgs& a, int block, i
       }
     })
     __syncthreads();
+    MP_NSTAMP(2)
 
     // ---- GEMM 2: IN: x = n @ Wx ; MID/LAST: n += t @ W3 + b3 ----------------------------------------------------
     MP_ZERO_ACC
@@ -256,6 +281,7 @@ __device__ __forceinline__ void schnet_node_body(const NodeArgs& a, int block, i
       })
     }
     gemm_tile<F, 2, RB>(Xb, lane, w_second, acc);
+    MP_NSTAMP(3)
     if constexpr (MODE == NODE_IN) {
       MP_FOR_OUT(cb, r, row, col, {
         if (node0 + row < a.N) a.x[(node0 + row) * F + col] = acc[rb][cb][r];
@@ -269,10 +295,12 @@ __device__ __forceinline__ void schnet_node_body(const NodeArgs& a, int block, i
         Xa[row * X_LD + col] = nn;
       })
       __syncthreads();
+      MP_NSTAMP(4)
 
       // ---- GEMM 3: MID: x = n @ Wx ; LAST: u = ssp(n @ Wl0 + bl0) ----------------------------------------------
       MP_ZERO_ACC
       gemm_tile<F, 2, RB>(Xa, lane, w_third, acc);
+      MP_NSTAMP(5)
       if constexpr (MODE == NODE_MID) {
         MP_FOR_OUT(cb, r, row, col, {
           if (node0 + row < a.N) a.x[(node0 + row) * F + col] = acc[rb][cb][r];
@@ -296,7 +324,13 @@ __device__ __forceinline__ void schnet_node_body(const NodeArgs& a, int block, i
       }
     }
     __syncthreads();  // Xa / Xb are reused by the next tile
+    MP_NSTAMP(6)
   }
+#ifdef MP_NODE_DIAG
+  if (tid == 0 && MODE == NODE_MID) {
+    for (int i = 0; i < 8; ++i) atomicAdd(&g_node_diag[i], dsum[i]);
+  }
+#endif
 }
 
 template <int MODE, int E, int RB, bool FAST>
@@ -387,6 +421,15 @@ int launch_node(const NodeArgs& a, int flags, hipStream_t s, const char* what) {
 }  // namespace
 
 extern "C" {
+
+#ifdef MP_NODE_DIAG
+int mp_debug_node_diag(unsigned long long* out8_host) {  // diagnostic build only: read and clear the phase sums
+  MP_HIP(hipMemcpyFromSymbol(out8_host, HIP_SYMBOL(g_node_diag), 64));
+  const unsigned long long zero[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  MP_HIP(hipMemcpyToSymbol(HIP_SYMBOL(g_node_diag), zero, 64));
+  return MP_OK;
+}
+#endif
 
 int mp_schnet_node_in_f32(const float* numbers, int64_t N, const float* emb, int vocab, int emb_dim, const float* W0,
                           const float* b0, const float* Wx, float* n_out, float* x_out, int flags, mpStream_t stream) {

@@ -1,9 +1,12 @@
-"""Phase breakdown of the SchNet node-update kernel (diagnostic build only: MP_LIB=.../lib_diag.so)."""
+"""Phase breakdown of the SchNet node-update kernel.  Needs the diagnostic library:
+
+    make -C gcnn_keras_amd/csrc diag && python scripts/probe_node_diag.py [graphs]
+"""
 import sys, os, ctypes
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
 from gcnn_keras_amd import _ffi, synth
-_ffi.LIB_PATH = os.path.abspath(os.environ["MP_LIB"])
+_ffi.LIB_PATH = os.path.abspath(os.environ.get("MP_LIB", os.path.join(os.path.dirname(_ffi.LIB_PATH), "libmpengine_diag.so")))
 from gcnn_keras_amd.engine import _HipTimer
 
 graphs = int(sys.argv[1]) if len(sys.argv) > 1 else 12500
