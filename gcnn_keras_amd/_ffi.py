@@ -86,6 +86,7 @@ _SIGNATURES = {
     "mp_bessel_basis_grad_f32": [P, c_int64, P, c_int, c_float, c_int, P, P, P],
     "mp_gauss_basis_grad_f32": [P, c_int64, c_int, c_float, c_float, c_float, P, P, P],
     "mp_cos_cutoff_grad_f32": [P, c_int64, c_float, P, P, P],
+    "mp_schnet_forward_launch": [P, P],
     "mp_pack_rows_host": [P, P, c_int64, c_int64, c_int, c_int, P, P, c_int],
     "mp_pack_edge_index_host": [P, c_int, P, P, c_int64, c_int, P, P, P, P, P, P, c_int],
     "mp_host_alloc": [c_size_t, c_int, P],
@@ -93,6 +94,21 @@ _SIGNATURES = {
     "mp_memcpy_h2d_async": [P, P, c_size_t, P],
 }
 _RESTYPES = {"mp_last_error": c_char_p}
+
+MP_SCHNET_MAX_DEPTH = 8
+
+
+class SchnetForwardDesc(ctypes.Structure):
+    """``mp_schnet_forward_desc`` of include/mpengine.h (field for field)."""
+    _fields_ = ([("N", c_int64), ("M", c_int64), ("G", c_int64),
+                 ("depth", ctypes.c_int32), ("vocab", ctypes.c_int32), ("flags", ctypes.c_int32),
+                 ("bins", ctypes.c_int32),
+                 ("g_distance", c_float), ("g_sigma", c_float), ("g_offset", c_float), ("reserved_", c_float)]
+                + [(name, c_void_p) for name in ("numbers", "xyz", "idx", "node_splits", "edge_splits", "embedding",
+                                                 "W0", "b0")]
+                + [(name, c_void_p * MP_SCHNET_MAX_DEPTH) for name in ("Wx", "packed", "W2", "b2", "W3", "b3")]
+                + [(name, c_void_p) for name in ("Wl0", "bl0", "Wl1", "bl1", "Wo0", "bo0", "Wo1", "bo1", "recv", "send",
+                                                 "dist", "flags_word", "n", "x", "agg", "h", "out")])
 
 _lib = None
 

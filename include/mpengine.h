@@ -286,6 +286,37 @@ int mp_gauss_basis_grad_f32(const float* d, int64_t M, int bins, float distance,
                             const float* gy, float* gd, mpStream_t stream);                         /* geom.py:567-571 */
 int mp_cos_cutoff_grad_f32(const float* d, int64_t n, float cutoff, const float* gy, float* gd, mpStream_t stream);
 
+/* The whole fused forward (kgcnn/literature/Schnet.py:104-148 with receiver-sorted edges) as ONE call: stage 0,
+ * depth x (cfconv + node update), last node chain, readout, launched in sequence on `stream` from a descriptor of the
+ * bound batch slot.  Equivalent to replaying a captured HIP graph of the same eight launches, without the capture:
+ * the entry for batches whose shapes change from call to call.  flags: bit0 fast softplus, bits 2-4 as
+ * mp_cfconv_fused_f32. */
+#define MP_SCHNET_MAX_DEPTH 8
+typedef struct mp_schnet_forward_desc {
+  int64_t N, M, G;
+  int32_t depth, vocab, flags, bins;
+  float g_distance, g_sigma, g_offset, reserved_;
+  const float* numbers;            /* (N) float node numbers */
+  const float* xyz;                /* (N,3) */
+  const int64_t* idx;              /* (M,2) sample indices */
+  const int64_t* node_splits;      /* (G+1) */
+  const int64_t* edge_splits;      /* (G+1) */
+  const float* embedding;          /* (vocab,64) */
+  const float* W0;                 /* (64,128) */
+  const float* b0;
+  const float* Wx[MP_SCHNET_MAX_DEPTH];      /* interaction i: dense1 (128,128), no bias */
+  const float* packed[MP_SCHNET_MAX_DEPTH];  /* interaction i: mp_cfconv_pack_f32 image */
+  const float* W2[MP_SCHNET_MAX_DEPTH];
+  const float* b2[MP_SCHNET_MAX_DEPTH];
+  const float* W3[MP_SCHNET_MAX_DEPTH];
+  const float* b3[MP_SCHNET_MAX_DEPTH];
+  const float* Wl0; const float* bl0; const float* Wl1; const float* bl1;   /* last_mlp */
+  const float* Wo0; const float* bo0; const float* Wo1; const float* bo1;   /* output_mlp */
+  int32_t* recv; int32_t* send; float* dist; int32_t* flags_word;           /* (M) work buffers, flag word */
+  float* n; float* x; float* agg; float* h; float* out;                     /* (N,128) x3 [agg zeroed], (N,64), (G,1) */
+} mp_schnet_forward_desc;
+int mp_schnet_forward_launch(const mp_schnet_forward_desc* desc_host, mpStream_t stream);
+
 /* ---------------------------------------------------------------- host batch packer ---------------------- */
 /* The data-format side of the path.  Host pointers only; nothing here launches a kernel.
  *

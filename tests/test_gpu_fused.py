@@ -189,3 +189,24 @@ def test_forwards_in_flight_are_independent_and_identical():
     got = outs[0].cpu().numpy()
     assert np.max(np.abs(got - ref)) <= 1e-5 * np.max(np.abs(ref))
     multi.check_flags()
+
+
+def test_direct_forward_launch_equals_graph_replay():
+    """``mp_schnet_forward_launch`` (one C-ABI call, no capture) issues the same eight launches as the captured graph."""
+    from gcnn_keras_amd.engine import SchnetForward
+    b = synth.qm9_like_batch(num_graphs=17, seed=33)
+    p = synth.schnet_params(seed=7, random_bias=True)
+    fwd = SchnetForward(p, depth=3, mode="fused", in_flight=1)
+    fwd.load_batch(b)
+    slot = fwd._slots[0]
+    replayed = slot.replay().clone()
+    torch.cuda.synchronize()
+    slot.out.zero_()
+    with torch.cuda.stream(slot.stream):
+        direct = slot.launch_direct().clone()
+    torch.cuda.synchronize()
+    assert torch.equal(direct, replayed)
+    ref = ko.schnet_forward(p, ko.R(b["node_number"], b["node_splits"]), ko.R(b["node_coordinates"], b["node_splits"]),
+                            ko.R(b["edge_indices"], b["edge_splits"]), depth=3)
+    assert np.max(np.abs(direct.cpu().numpy() - ref)) <= 1e-5 * np.max(np.abs(ref))
+    slot.check_flags()
