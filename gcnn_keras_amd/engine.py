@@ -233,6 +233,33 @@ class GraphedModel:
         return self.output
 
 
+class GraphedModelPool:
+    """Several ``GraphedModel`` replicas - one per batch slot, each with its own inputs, private graph memory and HIP
+    stream - so that forwards (or energy + force passes) of different batches overlap on the GPU, for ANY layer-path
+    model.  ``replay(i)`` launches slot ``i % in_flight`` on that slot's stream and returns its (static) output; call
+    ``wait(i)`` (or synchronise) before reading it from another stream."""
+
+    def __init__(self, model, inputs_per_slot, grad=None):
+        self.slots = [GraphedModel(model, inputs, grad=grad) for inputs in inputs_per_slot]
+        self.in_flight = len(self.slots)
+        self._events = [None] * self.in_flight
+
+    def replay(self, step=0):
+        k = step % self.in_flight
+        slot = self.slots[k]
+        with torch.cuda.stream(slot.stream):
+            slot.graph.replay()
+            ev = torch.cuda.Event()
+            ev.record()
+        self._events[k] = ev
+        return slot.output
+
+    def wait(self, step=0):
+        ev = self._events[step % self.in_flight]
+        if ev is not None:
+            torch.cuda.current_stream().wait_event(ev)
+
+
 def _fused_available():
     try:
         lib = _ffi.lib()
