@@ -9,7 +9,6 @@ Both go through the C ABI only; there is no CPU path.
 """
 import ctypes
 
-import numpy as np
 import torch
 
 from . import _ffi

@@ -9,7 +9,6 @@
 Every buffer is allocated when a batch is bound; ``forward()`` only replays the captured graph.
 """
 import ctypes
-import os
 
 import numpy as np
 import torch

@@ -3,7 +3,6 @@ import torch
 
 from .. import _ffi
 from ..ops.partition import change_partition_by_name
-from ..ragged import RaggedTensor
 from .base import GraphBaseLayer
 
 

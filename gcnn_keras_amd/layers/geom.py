@@ -4,7 +4,6 @@ import torch
 
 from .. import _ffi
 from ..ops.axis import get_positive_axis
-from ..ragged import RaggedTensor
 from .base import GraphBaseLayer
 from .gather import GatherNodesSelection
 from .modules import LazyMultiply, LazySubtract

@@ -8,7 +8,6 @@ import torch
 from .. import _ffi
 from ..ops.segment import reduce_op_code, segment_reduce_csr, segment_softmax_csr
 from ..ops.scatter import scatter_op_code
-from ..ragged import RaggedTensor
 from .base import GraphBaseLayer
 
 

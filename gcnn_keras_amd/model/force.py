@@ -11,7 +11,6 @@ import importlib
 import torch
 
 from ..layers.casting import ChangeTensorType
-from ..ragged import RaggedTensor
 
 
 def get_model_class(module_name: str, class_name: str):

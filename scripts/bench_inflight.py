@@ -1,7 +1,7 @@
 """Throughput of the fused SchNet forward with several forwards in flight (one HIP stream + graph + buffer set each)."""
 import sys, os, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-import numpy as np, torch
+import torch
 from gcnn_keras_amd import _ffi, synth
 if os.environ.get("MP_LIB"):
     _ffi.LIB_PATH = os.path.abspath(os.environ["MP_LIB"])

@@ -1,6 +1,6 @@
 """How much does the stream -> hardware-queue placement matter for batches in flight?  Re-draws the slots' streams from
 torch's pool and reports the throughput of each draw."""
-import sys, os, time, ctypes
+import sys, os, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from gcnn_keras_amd import synth

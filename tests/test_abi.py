@@ -1,6 +1,5 @@
 """The C-ABI library loads and exports every symbol include/mpengine.h declares; argument errors map to Python
 exceptions.  No compute is launched (runs without a GPU)."""
-import ctypes
 import os
 import re
 
