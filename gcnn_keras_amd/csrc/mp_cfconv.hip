@@ -142,11 +142,12 @@ __global__ __launch_bounds__(WAVES * 64, (WAVES == 4 && COMPACT) ? 2 : 1) void c
   };
   prefetch_tile(tile_first);
 
-  // ---- stage the pre-packed weights once per workgroup.  The small W1 image (17 KB) goes through registers and is
-  //      published by the first barrier - GEMM1 needs nothing else.  The 64 KB of W2 follow by LDS-DMA
-  //      (global_load_lds_dwordx4: 1 KB per wave instruction, no VGPRs), issued after that barrier so that no ordinary
-  //      load is pending beside them, and are awaited only right before the first GEMM2: their flight hides under the
-  //      first tile's sender-row loads, Gauss basis, GEMM1 and softplus. -----------------------------------------------
+  // ---- stage the pre-packed weights once per workgroup.  The small W1 image (11-17 KB) goes through registers; the
+  //      64 KB of W2 follow by LDS-DMA (global_load_lds_dwordx4: 1 KB per wave instruction, no VGPRs), issued after the
+  //      W1 loads have been consumed (vmcnt retires in order: an ordinary load waiting behind the DMA would wait for all
+  //      of it).  Neither is awaited here: the barrier that publishes W1 sits right before the first GEMM1 and the one
+  //      that publishes W2 right before the first GEMM2, so the first tile's index wait, sender shuffles and Gauss basis
+  //      run while the other waves' stores and the DMA are still in flight. ------------------------------------------------
   {
     const float4* src = reinterpret_cast<const float4*>(a.packed);
     float4* dst = reinterpret_cast<float4*>(lds);
@@ -155,7 +156,6 @@ __global__ __launch_bounds__(WAVES * 64, (WAVES == 4 && COMPACT) ? 2 : 1) void c
   float bias2[4];
 #pragma unroll
   for (int jb = 0; jb < 4; ++jb) bias2[jb] = a.packed[MAX_KROWS * F + F * F + 4 * c + jb];
-  __syncthreads();
   {
     constexpr int CHUNKS_PER_WAVE = (F * F / 256) / WAVES;  // 1-KB chunks of the W2 image per wave
     const float* src = a.packed + MAX_KROWS * F;
@@ -166,7 +166,8 @@ __global__ __launch_bounds__(WAVES * 64, (WAVES == 4 && COMPACT) ? 2 : 1) void c
                                        (__attribute__((address_space(3))) void*)(W2s + chunk * 256), 16, 0, 0);
     }
   }
-  bool w2_ready = false;  // wave-uniform: every wave passes the publishing barrier exactly once
+  bool w1_ready = false;  // wave-uniform: every wave passes each publishing barrier exactly once, W1's before W2's
+  bool w2_ready = false;
 
   MP_STAMP(0)
   const float* w1_lane = W1s + (nk * hh) * F + 4 * c;  // + s*F           : rows s (lo half) / nk+s (hi half)
@@ -233,6 +234,10 @@ __global__ __launch_bounds__(WAVES * 64, (WAVES == 4 && COMPACT) ? 2 : 1) void c
       }
     }
 
+    if (!w1_ready) {
+      __syncthreads();  // all four waves' parts of W1 are in LDS
+      w1_ready = true;
+    }
     MP_STAMP(1)
     // ---- GEMM1 (transposed): hT[f][e] = sum_k W1p[k][f] * rb[e][k]; lane = edge, register = feature ---------
     floatx16 h[4];
@@ -386,7 +391,8 @@ __global__ __launch_bounds__(WAVES * 64, (WAVES == 4 && COMPACT) ? 2 : 1) void c
     }
     MP_STAMP(7)
   }
-  if (!w2_ready) __syncthreads();  // a wave without tiles still owes the workgroup its barrier
+  if (!w1_ready) __syncthreads();  // a wave without tiles still owes the workgroup its two barriers
+  if (!w2_ready) __syncthreads();
   if constexpr (DIAG) {
     if (lane == 0 && a.diag) {
 #pragma unroll
