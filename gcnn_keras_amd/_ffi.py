@@ -86,6 +86,7 @@ _SIGNATURES = {
     "mp_bessel_basis_grad_f32": [P, c_int64, P, c_int, c_float, c_int, P, P, P],
     "mp_gauss_basis_grad_f32": [P, c_int64, c_int, c_float, c_float, c_float, P, P, P],
     "mp_cos_cutoff_grad_f32": [P, c_int64, c_float, P, P, P],
+    "mp_layer_norm_f32": [P, c_int64, c_int64, P, P, c_float, P, P],
     "mp_schnet_forward_launch": [P, P],
     "mp_pack_rows_host": [P, P, c_int64, c_int64, c_int, c_int, P, P, c_int],
     "mp_pack_edge_index_host": [P, c_int, P, P, c_int64, c_int, P, P, P, P, P, P, c_int],

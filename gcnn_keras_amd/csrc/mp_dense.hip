@@ -107,9 +107,50 @@ __global__ void softmax_rows_kernel(const float* __restrict__ x, int64_t R, int6
   }
 }
 
+// Keras LayerNormalization over the last axis (kgcnn/layers/norm.py:60-63, 94-105 on the values of a ragged tensor):
+// mean and biased variance of each row (tf.nn.moments: variance as the mean squared difference from the mean), then
+// x * inv + (beta - mean * inv) with inv = rsqrt(var + eps) * gamma (the tf.nn.batch_normalization form Keras uses).
+// One wave per row; the row is read twice (L2-resident), reduced with wave shuffles.
+__global__ void layer_norm_rows_kernel(const float* __restrict__ x, int64_t R, int64_t C,
+                                       const float* __restrict__ gamma, const float* __restrict__ beta, float eps,
+                                       float* __restrict__ out) {
+  const int lane = threadIdx.x & 63;
+  const int64_t wave_global = (static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x) >> 6;
+  const int64_t nwaves = (static_cast<int64_t>(gridDim.x) * blockDim.x) >> 6;
+  const float inv_c = 1.0f / static_cast<float>(C);
+  for (int64_t r = wave_global; r < R; r += nwaves) {
+    const float* row = x + r * C;
+    float sum = 0.0f;
+    for (int64_t c = lane; c < C; c += 64) sum += row[c];
+    for (int o = 32; o > 0; o >>= 1) sum += __shfl_xor(sum, o, 64);
+    const float mean = sum * inv_c;
+    float sq = 0.0f;
+    for (int64_t c = lane; c < C; c += 64) {
+      const float d = row[c] - mean;
+      sq += d * d;
+    }
+    for (int o = 32; o > 0; o >>= 1) sq += __shfl_xor(sq, o, 64);
+    const float rstd = rsqrtf(sq * inv_c + eps);
+    for (int64_t c = lane; c < C; c += 64) {
+      const float inv = gamma ? rstd * gamma[c] : rstd;
+      const float shift = (beta ? beta[c] : 0.0f) - mean * inv;
+      out[r * C + c] = row[c] * inv + shift;
+    }
+  }
+}
+
 }  // namespace
 
 extern "C" {
+
+int mp_layer_norm_f32(const float* x, int64_t R, int64_t C, const float* gamma, const float* beta, float epsilon,
+                      float* out, mpStream_t stream) {
+  MP_REQUIRE(R >= 0 && C >= 1, "mp_layer_norm_f32: bad sizes");
+  if (R == 0) return MP_OK;
+  MP_REQUIRE(x && out, "mp_layer_norm_f32: null pointer");
+  layer_norm_rows_kernel<<<mp::grid_for(R * 64), 256, 0, mp::as_stream(stream)>>>(x, R, C, gamma, beta, epsilon, out);
+  return mp::check_launch("mp_layer_norm_f32");
+}
 
 int mp_dense_f32(const float* x, int64_t R, int64_t K, const float* W, const float* b, int64_t U, int act,
                  float act_alpha, float* out, mpStream_t stream) {

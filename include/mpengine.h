@@ -152,6 +152,10 @@ int mp_dense_f32(const float* x, int64_t R, int64_t K, const float* W, const flo
 
 int mp_activation_f32(int act, float act_alpha, const float* x, int64_t n, float* out, mpStream_t stream);
 int mp_softmax_rows_f32(const float* x, int64_t R, int64_t C, float* out, mpStream_t stream);
+/* GraphLayerNormalization over the last axis of the values (kgcnn/layers/norm.py:8-110 = Keras LayerNormalization):
+ * out = (x - mean_row) * rsqrt(var_row + epsilon) * gamma + beta, biased variance; gamma / beta (C) nullable. */
+int mp_layer_norm_f32(const float* x, int64_t R, int64_t C, const float* gamma, const float* beta, float epsilon,
+                      float* out, mpStream_t stream);
 
 /* Broadcasting binary op on (R, D1, D2) views: operand strides in elements, 0 = broadcast
  * (LazyAdd/LazySubtract/LazyMultiply of kgcnn/layers/modules.py:187-301, incl. PaiNN's (M,1,F)*(M,3,F)). */

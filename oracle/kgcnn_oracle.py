@@ -883,6 +883,43 @@ def dmpnn_pooling_edges_directed(nodes, edges, idx, reverse_pair):
     return R(ed_new.values - ed_not.values, ed_new.row_splits)
 
 
+def layer_normalization(x, gamma=None, beta=None, epsilon=1e-3):
+    """Keras ``LayerNormalization`` over the last axis, as ``GraphLayerNormalization`` applies it to the values
+    (kgcnn/layers/norm.py:60-63, 94-105): moments with the variance as mean squared difference, then the
+    ``tf.nn.batch_normalization`` form ``x * inv + (beta - mean * inv)``, ``inv = rsqrt(var + eps) * gamma``."""
+    x = np.asarray(x)
+    mean = np.mean(x, axis=-1, keepdims=True, dtype=x.dtype)
+    var = np.mean(np.square(x - mean), axis=-1, keepdims=True, dtype=x.dtype)
+    inv = (np.asarray(1, x.dtype) / np.sqrt(var + np.asarray(epsilon, x.dtype))).astype(x.dtype)
+    if gamma is not None:
+        inv = inv * gamma
+    shift = -mean * inv
+    if beta is not None:
+        shift = beta + shift
+    return (x * inv + shift).astype(x.dtype)
+
+
+def graph_sage_node_layer(node, idx, p, edge=None, act="relu", pooling_method="sum"):
+    """``GraphSageNodeLayer.call``, kgcnn/layers/conv/sage_conv.py:83-100.  ``p``: nb/{kernel,bias}, self/{kernel,bias},
+    norm/{gamma,beta}."""
+    msg = gather_nodes_outgoing(node, idx)
+    if edge is not None:
+        msg = lazy_concatenate([msg, edge], axis=-1)
+    msg = dense(msg, p["nb/kernel"], p.get("nb/bias"), act)
+    nu = pooling_local_edges(node, msg, idx, pooling_method=pooling_method)
+    n = dense(lazy_concatenate([node, nu], axis=-1), p["self/kernel"], p.get("self/bias"), act)
+    return R(layer_normalization(n.values, p.get("norm/gamma"), p.get("norm/beta")), n.row_splits)
+
+
+def graph_sage_edge_update_layer(node, edge, idx, p, act="relu", use_normalization=True):
+    """``GraphSageEdgeUpdateLayer.call``, kgcnn/layers/conv/sage_conv.py:179-185."""
+    pair = gather_nodes(node, idx)
+    ed = dense(lazy_concatenate([edge, pair], axis=-1), p["mlp/kernel"], p.get("mlp/bias"), act)
+    if use_normalization:
+        ed = R(layer_normalization(ed.values, p.get("norm/gamma"), p.get("norm/beta")), ed.row_splits)
+    return ed
+
+
 def megnet_block(node, edge, idx, env, p, act="kgcnn>softplus2", pooling_method="mean"):
     """``MEGnetBlock.call``, kgcnn/layers/conv/megnet_conv.py:96-120.  ``env`` is a dense ``(G, Fu)`` array; ``p`` holds
     phi_e{,_1,_2}/phi_n{,_1,_2}/phi_u{,_1,_2} kernels and biases.  Returns ``(nodes, edges, env)``."""

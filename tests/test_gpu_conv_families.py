@@ -215,3 +215,63 @@ def test_softplus2_activation_and_megnet_block():
     _close(up.cpu().numpy(), ru, tol=2e-5)
     cfg = block.get_config()
     assert cfg["activation"] == "kgcnn>softplus2" and cfg["pooling_method"] == "mean" and cfg["env_embed"] == [16, 16, 14]
+
+
+def test_graph_layer_normalization():
+    from gcnn_keras_amd.layers.norm import GraphLayerNormalization
+    from gcnn_keras_amd.ragged import RaggedTensor
+    rng = np.random.default_rng(2)
+    for width in (1, 7, 64, 128, 200):
+        x = (rng.normal(size=(37, width)) * 3 + 1.5).astype(np.float32)
+        gamma, beta = rng.uniform(0.5, 1.5, width).astype(np.float32), rng.normal(size=width).astype(np.float32)
+        layer = GraphLayerNormalization(epsilon=1e-3)
+        rt = RaggedTensor.from_numpy(x, np.array([0, 10, 10, 37]))
+        layer(rt)
+        layer.set_weights([gamma, beta])
+        got = layer(rt).values.cpu().numpy()
+        _close(got, ko.layer_normalization(x, gamma, beta, 1e-3), tol=2e-5)
+        ref64 = ko.layer_normalization(x.astype(np.float64), gamma.astype(np.float64), beta.astype(np.float64), 1e-3)
+        assert np.max(np.abs(got - ref64)) <= 2e-5 * max(1.0, np.max(np.abs(ref64)))
+    plain = GraphLayerNormalization(center=False, scale=False)
+    out = plain(RaggedTensor.from_numpy(x, np.array([0, 37]))).values.cpu().numpy()
+    _close(out, ko.layer_normalization(x), tol=2e-5)
+    assert plain.get_config()["axis"] == 2 and plain.weights == []        # positive axis after build (norm.py:89-90)
+    with pytest.raises(ValueError):
+        GraphLayerNormalization(axis=0)
+
+
+@pytest.mark.parametrize("use_edges", [False, True])
+def test_graph_sage_layers(use_edges):
+    from gcnn_keras_amd.layers.conv.sage_conv import GraphSageEdgeUpdateLayer, GraphSageNodeLayer
+    b = _batch(num_graphs=8, seed=31, f=24, fe=12)
+    rng = np.random.default_rng(13)
+    units = 40
+    fin_nb = 24 + (12 if use_edges else 0)
+    p = {"nb/kernel": synth.glorot_uniform(rng, fin_nb, units), "nb/bias": (rng.normal(size=units) * 0.1).astype(np.float32),
+         "self/kernel": synth.glorot_uniform(rng, 24 + units, units),
+         "self/bias": (rng.normal(size=units) * 0.1).astype(np.float32),
+         "norm/gamma": rng.uniform(0.5, 1.5, units).astype(np.float32), "norm/beta": rng.normal(size=units).astype(np.float32)}
+    node, edge = _dev(b["x"], b["node_splits"]), _dev(b["e"], b["edge_splits"])
+    index = _dev(b["edge_indices"], b["edge_splits"])
+    layer = GraphSageNodeLayer(units, use_edge_features=use_edges, pooling_method="mean")
+    inputs = [node, edge, index] if use_edges else [node, index]
+    layer(inputs)
+    layer.set_weights([p["nb/kernel"], p["nb/bias"], p["self/kernel"], p["self/bias"], p["norm/gamma"], p["norm/beta"]])
+    got = layer(inputs)
+    ref = ko.graph_sage_node_layer(ko.R(b["x"], b["node_splits"]), ko.R(b["edge_indices"], b["edge_splits"]), p,
+                                   edge=ko.R(b["e"], b["edge_splits"]) if use_edges else None, pooling_method="mean")
+    _close(got.values.cpu().numpy(), ref.values, tol=3e-5)
+    cfg = layer.get_config()
+    assert cfg["units"] == units and cfg["pooling_method"] == "mean" and cfg["activation"] == ["relu"]
+
+    q = {"mlp/kernel": synth.glorot_uniform(rng, 12 + 2 * 24, units), "mlp/bias": (rng.normal(size=units) * 0.1).astype(np.float32),
+         "norm/gamma": p["norm/gamma"], "norm/beta": p["norm/beta"]}
+    elayer = GraphSageEdgeUpdateLayer(units, use_normalization=use_edges)
+    elayer([node, edge, index])
+    elayer.set_weights([q["mlp/kernel"], q["mlp/bias"]] + ([q["norm/gamma"], q["norm/beta"]] if use_edges else []))
+    egot = elayer([node, edge, index])
+    eref = ko.graph_sage_edge_update_layer(ko.R(b["x"], b["node_splits"]), ko.R(b["e"], b["edge_splits"]),
+                                           ko.R(b["edge_indices"], b["edge_splits"]), q, use_normalization=use_edges)
+    _close(egot.values.cpu().numpy(), eref.values, tol=3e-5)
+    with pytest.raises(NotImplementedError):
+        GraphSageNodeLayer(8, pooling_method="LSTM")
