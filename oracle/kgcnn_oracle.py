@@ -865,6 +865,31 @@ def attention_head_gatv2(node, edge, idx, p, act="kgcnn>leaky_relu", use_edge_fe
     return h_i
 
 
+def gat_forward(params, node_attr, edge_attr, idx, depth=3, heads=5, concat_heads=False, v2=False,
+                act="kgcnn>leaky_relu", use_edge_features=True, use_final_activation=False,
+                pooling_method="mean", output_mlp_act=("relu", "relu", "sigmoid")):
+    """``kgcnn.literature.GAT.make_model`` / ``GATv2.make_model`` forward with feature inputs and
+    ``output_embedding='graph'`` (kgcnn/literature/GAT.py:89-112).  ``params``: dense0/{kernel,bias},
+    block{i}/head{h}/<head params>, output_mlp/{k}/{kernel,bias}."""
+    head_fn = attention_head_gatv2 if v2 else attention_head_gat
+    nk = dense(node_attr, params["dense0/kernel"], params.get("dense0/bias"), "linear")
+    for i in range(depth):
+        outs = [head_fn(nk, edge_attr, idx, _sub(params, "block%d/head%d/" % (i, h)), act=act,
+                        use_edge_features=use_edge_features, use_final_activation=use_final_activation)
+                for h in range(heads)]
+        if concat_heads:
+            nk = lazy_concatenate(outs, axis=-1)
+        else:
+            acc = outs[0].values
+            for o in outs[1:]:
+                acc = acc + o.values
+            mean = acc / np.asarray(len(outs), acc.dtype)      # LazyAverage, kgcnn/layers/modules.py
+            nk = R(activation(act, mean), outs[0].row_splits)
+    pooled = pooling_nodes(nk, pooling_method=pooling_method)
+    return mlp(pooled, [(params["output_mlp/%d/kernel" % k], params.get("output_mlp/%d/bias" % k), output_mlp_act[k])
+                        for k in range(len(output_mlp_act))])
+
+
 def dmpnn_gather_edges_pairs(edges, pair_index):
     """``DMPNNGatherEdgesPairs.call``, kgcnn/layers/conv/dmpnn_conv.py:39-46: reverse-edge rows, zeros where the pair
     index is negative."""

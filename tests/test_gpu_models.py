@@ -233,3 +233,55 @@ def test_graphed_model_pool_overlaps_batches_of_a_layer_path_model():
     torch.cuda.synchronize()
     t_one = (time.perf_counter() - t0) / 60
     print("PaiNN forward (8 graphs): one graph at a time %.0f us, three in flight %.0f us per forward" % (t_one * 1e6, t_pool * 1e6))
+
+
+@pytest.mark.parametrize("v2,concat", [(False, False), (False, True), (True, False)])
+def test_gat_builders_forward(v2, concat):
+    """``GAT.make_model`` / ``GATv2.make_model`` (kgcnn/literature/GAT.py:89-121) with feature inputs vs the oracle."""
+    from gcnn_keras_amd.literature import GAT, GATv2
+    from gcnn_keras_amd.ragged import RaggedTensor
+    b = synth.qm9_like_batch(num_graphs=6, seed=17)
+    rng = np.random.default_rng(18)
+    n, m = int(b["node_splits"][-1]), int(b["edge_splits"][-1])
+    fn, fe, units, heads, depth = 12, 6, 16, 3, 2
+    x = rng.normal(size=(n, fn)).astype(np.float32)
+    e = rng.normal(size=(m, fe)).astype(np.float32)
+    builder = GATv2 if v2 else GAT
+    model = builder.make_model(
+        inputs=[{"shape": (None, fn), "name": "node_attributes", "dtype": "float32", "ragged": True},
+                {"shape": (None, fe), "name": "edge_attributes", "dtype": "float32", "ragged": True},
+                {"shape": (None, 2), "name": "edge_indices", "dtype": "int64", "ragged": True}],
+        attention_args={"units": units}, depth=depth, attention_heads_num=heads, attention_heads_concat=concat)
+    # random weights in model order -> oracle parameter dict
+    p, arrays = {}, []
+    def add(key, shape, bias=False):
+        a = (rng.normal(size=shape) * 0.1).astype(np.float32) if bias else synth.glorot_uniform(rng, shape[0], shape[1])
+        p[key] = a
+        arrays.append(a)
+    arrays += [w.cpu().numpy() for _, w in model.layers[0].weights] + [w.cpu().numpy() for _, w in model.layers[1].weights]
+    add("dense0/kernel", (fn, units)); add("dense0/bias", (units,), True)
+    width = units
+    for i in range(depth):
+        for h in range(heads):
+            pre = "block%d/head%d/" % (i, h)
+            add(pre + "linear_trafo/kernel", (width, units)); add(pre + "linear_trafo/bias", (units,), True)
+            if v2:
+                add(pre + "alpha_activation/kernel", (2 * width + fe, units))
+                add(pre + "alpha_activation/bias", (units,), True)
+                add(pre + "alpha/kernel", (units, 1))
+            else:
+                add(pre + "alpha/kernel", (2 * units + fe, 1))
+        width = units * heads if concat else units
+    for k, (fin, fout, has_bias) in enumerate(((width, 25, True), (25, 10, True), (10, 1, False))):
+        add("output_mlp/%d/kernel" % k, (fin, fout))
+        if has_bias:
+            add("output_mlp/%d/bias" % k, (fout,), True)
+    model.set_weights(arrays)
+    out = model([RaggedTensor.from_numpy(x, b["node_splits"]), RaggedTensor.from_numpy(e, b["edge_splits"]),
+                 RaggedTensor.from_numpy(b["edge_indices"], b["edge_splits"])]).cpu().numpy()
+    ref = ko.gat_forward(p, ko.R(x, b["node_splits"]), ko.R(e, b["edge_splits"]), ko.R(b["edge_indices"], b["edge_splits"]),
+                         depth=depth, heads=heads, concat_heads=concat, v2=v2)
+    assert out.shape == (6, 1)
+    assert np.max(np.abs(out - ref)) <= 2e-5 * max(1.0, np.max(np.abs(ref)))
+    with pytest.raises(ValueError):
+        builder.make_model(not_a_kwarg=1)
