@@ -8,7 +8,7 @@ weighted segment sum - csrc/mp_segment.hip); they differ in how the logit is for
 """
 from ..base import GraphBaseLayer
 from ..gather import GatherNodesIngoing, GatherNodesOutgoing
-from ..modules import Activation, Dense, LazyConcatenate
+from ..modules import Activation, Dense, LazyAverage, LazyConcatenate
 from ..pooling import PoolingLocalEdgesAttention
 
 _KERNEL_KEYS = ("kernel_regularizer", "activity_regularizer", "bias_regularizer", "kernel_constraint", "bias_constraint",
@@ -107,3 +107,49 @@ class AttentionHeadGATV2(_AttentionHead):
         wn_out = self.lay_gather_out([w_n, edge_index], **kwargs)
         hidden = self.lay_alpha_activation(self._pair_features(n_in, n_out, edge, **kwargs), **kwargs)
         return self._attend(node, wn_out, self.lay_alpha(hidden, **kwargs), edge_index, **kwargs)
+
+
+class MultiHeadGATV2Layer(AttentionHeadGATV2):
+    r"""``num_heads`` GATv2 heads in one layer that also hands back the attention logits
+    (kgcnn/layers/conv/gat_conv.py:233-323; MEGAN consumes the logits as edge importances).
+
+    Returns ``(h, a)``: node embeddings ``(batch, [N], units * num_heads)`` (``concat_heads``) or their average
+    ``(batch, [N], units)``, and the logits of all heads ``(batch, [M], num_heads, 1)``.  Like the reference, every head
+    owns three Dense layers (``units`` with the activation, ``units`` with the activation, ``1`` linear) and reuses the
+    base class's gathers, concatenation, attention pooling and optional final activation."""
+
+    def __init__(self, units: int, num_heads: int, activation: str = "kgcnn>leaky_relu", use_bias: bool = True,
+                 concat_heads: bool = True, **kwargs):
+        super().__init__(units=units, activation=activation, use_bias=use_bias, **kwargs)
+        self.num_heads = int(num_heads)
+        self.concat_heads = concat_heads
+        self.head_layers = []
+        for _ in range(self.num_heads):
+            self.head_layers += [Dense(units, activation=activation, use_bias=use_bias),
+                                 Dense(units, activation=activation, use_bias=use_bias),
+                                 Dense(1, activation="linear", use_bias=False)]
+        self.lay_combine_heads = LazyConcatenate(axis=-1) if concat_heads else LazyAverage()
+
+    def call(self, inputs, **kwargs):
+        """inputs: ``[nodes, edges, edge_index]`` -> ``(node embeddings, attention logits)``."""
+        node, edge, edge_index = inputs
+        n_in = self.lay_gather_in([node, edge_index], **kwargs)
+        n_out = self.lay_gather_out([node, edge_index], **kwargs)
+        pair = self._pair_features(n_in, n_out, edge, **kwargs)       # identical for every head
+        logits, embeddings = [], []
+        for k in range(self.num_heads):
+            lay_linear, lay_alpha_activation, lay_alpha = self.head_layers[3 * k:3 * k + 3]
+            wn_out = self.lay_gather_out([lay_linear(node, **kwargs), edge_index], **kwargs)
+            a_ij = lay_alpha(lay_alpha_activation(pair, **kwargs), **kwargs)                     # (batch, [M], 1)
+            embeddings.append(self._attend(node, wn_out, a_ij, edge_index, **kwargs))
+            logits.append(a_ij)
+        # the reference expands every head's logits to (batch, [M], 1, 1) and concatenates on axis -2; with a trailing
+        # unit axis that is the last-axis concatenation of the (batch, [M], 1) logits, reshaped
+        stacked = self.lay_concat(logits, **kwargs)
+        stacked = stacked.with_values(stacked.values.unsqueeze(-1))                              # (batch, [M], K, 1)
+        return self.lay_combine_heads(embeddings, **kwargs), stacked
+
+    def get_config(self):
+        config = super().get_config()
+        config.update({"num_heads": self.num_heads, "concat_heads": self.concat_heads})
+        return config

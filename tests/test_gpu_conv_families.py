@@ -275,3 +275,46 @@ def test_graph_sage_layers(use_edges):
     _close(egot.values.cpu().numpy(), eref.values, tol=3e-5)
     with pytest.raises(NotImplementedError):
         GraphSageNodeLayer(8, pooling_method="LSTM")
+
+
+def test_multi_head_gatv2_layer_reference_shape_contract_and_values():
+    # reference test/test_conv_attention.py:84-104 (shapes, both head-combination modes) + values vs single heads
+    from gcnn_keras_amd.layers.base import GraphBaseLayer
+    from gcnn_keras_amd.layers.conv.gat_conv import MultiHeadGATV2Layer
+    from gcnn_keras_amd.ragged import RaggedTensor
+    layer = MultiHeadGATV2Layer(units=2, num_heads=2)
+    assert isinstance(layer, MultiHeadGATV2Layer) and isinstance(layer, GraphBaseLayer)
+    rng = np.random.default_rng(1)
+    sizes = [(int(rng.integers(5, 31)),) for _ in range(5)]
+    n_rows, e_rows, ei_rows = [], [], []
+    for (nn_,) in sizes:
+        m = int(rng.integers(1, nn_))
+        n_rows.append(rng.random((nn_, 3)).astype(np.float32))
+        e_rows.append(rng.random((m, 3)).astype(np.float32))
+        ei_rows.append(np.stack([rng.permutation(nn_)[:m], rng.permutation(nn_)[:m]], axis=1).astype(np.int64))
+    n = RaggedTensor.from_nested(n_rows, np.float32, (3,))
+    e = RaggedTensor.from_nested(e_rows, np.float32, (3,))
+    ei = RaggedTensor.from_nested(ei_rows, np.int64, (2,))
+    num_units, num_heads = 2, 4
+    layer = MultiHeadGATV2Layer(units=num_units, num_heads=num_heads, concat_heads=True)
+    emb, logits = layer([n, e, ei])
+    assert isinstance(emb, RaggedTensor) and isinstance(logits, RaggedTensor)
+    assert emb.shape == (5, None, num_units * num_heads) and logits.shape == (5, None, num_heads, 1)
+    # values: head k of the layer == an AttentionHeadGATV2-style computation with that head's weights (oracle)
+    ws = layer.get_weights()
+    per_head = [ws[5 * k:5 * k + 5] for k in range(num_heads)]    # linear k,b ; alpha_act k,b ; alpha k  (creation order)
+    for k, (lk, lb, ak, ab, al) in enumerate(per_head):
+        # the multi-head layer's per-head linear transform carries the activation (gat_conv.py:257), the single head's
+        # does not - so the reference is rebuilt from the oracle's primitives rather than from attention_head_gatv2
+        w_n = ko.dense(ko.R(n.values.cpu().numpy(), n.row_splits_host()), lk, lb, "kgcnn>leaky_relu")
+        idx_r = ko.R(ei.values.cpu().numpy(), ei.row_splits_host())
+        node_r = ko.R(n.values.cpu().numpy(), n.row_splits_host())
+        pair = ko.lazy_concatenate([ko.gather_nodes_ingoing(node_r, idx_r), ko.gather_nodes_outgoing(node_r, idx_r)])
+        a = ko.dense(ko.dense(pair, ak, ab, "kgcnn>leaky_relu"), al, None, "linear")
+        h = ko.pooling_local_edges_attention(node_r, ko.gather_nodes_outgoing(w_n, idx_r), a, idx_r)
+        h = ko.activation("kgcnn>leaky_relu", h.values)
+        _close(emb.values.cpu().numpy()[:, k * num_units:(k + 1) * num_units], h, tol=2e-5)
+        _close(logits.values.cpu().numpy()[:, k, :], a.values, tol=2e-5)
+    layer = MultiHeadGATV2Layer(units=num_units, num_heads=num_heads, concat_heads=False)
+    emb, logits = layer([n, e, ei])
+    assert emb.shape == (5, None, num_units) and logits.shape == (5, None, num_heads, 1)
