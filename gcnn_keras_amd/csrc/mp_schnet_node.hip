@@ -138,6 +138,9 @@ __device__ __forceinline__ void schnet_node_body(const NodeArgs& a, int block, i
   //      and the next tile's rows are requested while the current tile computes. ------------------------------------
   constexpr int TN = 16 * RB;
   constexpr bool EARLY_STAGE = RB == 1;
+  // larger tiles: the next tile's rows are requested before the LAST big GEMM of the current tile (GEMM 3; GEMM 2 for the
+  // input chain), into the registers that held the residual rows until the epilogue before it - no extra pressure
+  constexpr bool LATE_STAGE = !EARLY_STAGE;
   constexpr int SV_IN = (TN * E) / 256;      // floats per thread (NODE_IN: embedding rows)
   constexpr int SV = (TN * F / 4) / 256;     // float4 per thread (aggregation rows)
   float stg_in[MODE == NODE_IN ? SV_IN : 1];
@@ -189,7 +192,7 @@ __device__ __forceinline__ void schnet_node_body(const NodeArgs& a, int block, i
       }
     }
   };
-  if constexpr (EARLY_STAGE) stage_load(block);
+  stage_load(block);
 
   // ---- weight slices -> registers (once per persistent workgroup) -------------------------------------------
   float w_first[2][(MODE == NODE_IN ? E : F) / 4];   // IN: W0 ; MID/LAST: W2
@@ -233,12 +236,7 @@ __device__ __forceinline__ void schnet_node_body(const NodeArgs& a, int block, i
     MP_NSTAMP(7)
 
     // ---- stage the input tile into Xa (coalesced; the consumed aggregation rows were re-zeroed by stage_load) --------
-    if constexpr (EARLY_STAGE) {
-      stage_store();
-    } else {
-      stage_load(tile);
-      stage_store();
-    }
+    stage_store();   // the rows were requested during the previous tile (or before the loop)
     __syncthreads();
     MP_NSTAMP(0)
 
@@ -275,6 +273,7 @@ __device__ __forceinline__ void schnet_node_body(const NodeArgs& a, int block, i
 
     // ---- GEMM 2: IN: x = n @ Wx ; MID/LAST: n += t @ W3 + b3 ----------------------------------------------------
     MP_ZERO_ACC
+    if constexpr (MODE == NODE_IN && LATE_STAGE) stage_load(tile + nblocks);
     if constexpr (MODE != NODE_IN && !N_EARLY) {
       MP_FOR_OUT(cb, r, row, col, {
         n_res[rb][cb][r] = (node0 + row < a.N) ? a.n[(node0 + row) * F + col] : 0.0f;
@@ -299,6 +298,7 @@ __device__ __forceinline__ void schnet_node_body(const NodeArgs& a, int block, i
 
       // ---- GEMM 3: MID: x = n @ Wx ; LAST: u = ssp(n @ Wl0 + bl0) ----------------------------------------------
       MP_ZERO_ACC
+      if constexpr (LATE_STAGE) stage_load(tile + nblocks);
       gemm_tile<F, 2, RB>(Xa, lane, w_third, acc);
       MP_NSTAMP(5)
       if constexpr (MODE == NODE_MID) {
