@@ -393,23 +393,17 @@ __global__ __launch_bounds__(256) void schnet_readout_kernel(const float* __rest
   }
 }
 
-// Small batches (every 16-node tile gets a workgroup of its own on the 256 CUs) are latency bound: 16-node tiles.
-// Large batches are throughput bound: 32-node tiles (each weight register feeds 2 MFMAs) and two workgroups per CU so
-// that one tile's barriers / epilogue hide under the other's MFMAs.  64-node tiles measured slower (3686 vs 3580 us per
-// forward at 225 k nodes, 452 vs 407 us at 18 k): next to 32 accumulator and 32 staging registers the three resident
-// weight slices no longer fit 256 registers and are reloaded from scratch inside the MFMA loop.
+// 16-node tiles for every batch size: the build whose three weight slices, accumulators, staging and residual rows fit
+// 250 registers without spills, with the next tile's rows and the residual rows in flight during the GEMMs.  Larger
+// tiles (each weight register feeding 2 or 4 MFMAs) were measured slower once the epilogue's load-after-store
+// serialisation was gone - 64-node tiles spill the weights, 32-node tiles spill ~25 registers whose reloads queue behind
+// the tile prefetch (3371 vs 3328 us per forward at 225 k nodes, 397 vs 380 us at 18 k).  The persistent grid is two
+// workgroups per CU.
 template <int MODE, int E, bool FAST>
 int launch_node_impl(NodeArgs a, hipStream_t s, const char* what) {
-  const int64_t tiles16 = (a.N + 15) / 16;
-  if (tiles16 <= 1024) {
-    a.ntiles = static_cast<int>(tiles16);
-    const int grid = a.ntiles < 512 ? a.ntiles : 512;
-    schnet_node_kernel<MODE, E, 1, FAST><<<grid, 256, 0, s>>>(a);
-  } else {
-    a.ntiles = static_cast<int>((a.N + 31) / 32);
-    const int grid = a.ntiles < 512 ? a.ntiles : 512;
-    schnet_node_kernel<MODE, E, 2, FAST><<<grid, 256, 0, s>>>(a);
-  }
+  a.ntiles = static_cast<int>((a.N + 15) / 16);
+  const int grid = a.ntiles < 512 ? a.ntiles : 512;
+  schnet_node_kernel<MODE, E, 1, FAST><<<grid, 256, 0, s>>>(a);
   return mp::check_launch(what);
 }
 
