@@ -7,7 +7,7 @@
 //   readout: PoolingNodes(sum) + MLP([64, 1])            Schnet.py:133-135
 //
 // These chains are latency bound at QM9 batch sizes (2301 nodes = 144 tiles of 16): four waves of a workgroup
-// cooperate on one tile (16 nodes for small N, 32 for large N), each wave producing a 32-column slice of every GEMM with v_mfma_f32_16x16x4_f32 (two
+// cooperate on one 16-node tile, each wave producing a 32-column slice of every GEMM with v_mfma_f32_16x16x4_f32 (two
 // independent 16x16 accumulators per wave cover its 40-cycle dependent latency).  The wave keeps its slice of
 // every weight matrix in REGISTERS for the life of the persistent workgroup (64 VGPRs per 128x32 slice, loaded
 // once with coalesced 64-B reads), so the only LDS traffic is the 16x128 activation tile handed from one GEMM to
