@@ -210,3 +210,33 @@ def test_direct_forward_launch_equals_graph_replay():
                             ko.R(b["edge_indices"], b["edge_splits"]), depth=3)
     assert np.max(np.abs(direct.cpu().numpy() - ref)) <= 1e-5 * np.max(np.abs(ref))
     slot.check_flags()
+
+
+def test_slots_with_unsorted_receivers_and_direct_launch_fallback():
+    """Batches whose receivers are not sorted take the stable-sort route inside every slot; ``launch_direct`` (built for
+    sorted batches) must fall back to the graph replay and still return the same bits."""
+    from gcnn_keras_amd.engine import SchnetForward
+    b = synth.qm9_like_batch(num_graphs=11, seed=8)
+    rng = np.random.default_rng(1)
+    idx = b["edge_indices"].copy()
+    for g in range(11):
+        lo, hi = b["edge_splits"][g], b["edge_splits"][g + 1]
+        idx[lo:hi] = idx[lo:hi][rng.permutation(hi - lo)]
+    b["edge_indices"] = idx
+    p = synth.schnet_params(seed=7, random_bias=True)
+    fwd = SchnetForward(p, depth=3, mode="fused", in_flight=2)
+    fwd.load_batch(b)
+    assert not fwd._slots[0].sorted
+    for i in range(6):
+        fwd.replay(i)
+    torch.cuda.synchronize()
+    a, c = fwd._slots[0].out.clone(), fwd._slots[1].out.clone()
+    assert torch.equal(a, c)
+    with torch.cuda.stream(fwd._slots[0].stream):
+        d = fwd._slots[0].launch_direct().clone()
+    torch.cuda.synchronize()
+    assert torch.equal(d, a)
+    ref = ko.schnet_forward(p, ko.R(b["node_number"], b["node_splits"]), ko.R(b["node_coordinates"], b["node_splits"]),
+                            ko.R(b["edge_indices"], b["edge_splits"]), depth=3)
+    assert _rel_err(a.cpu().numpy(), ref) <= 1e-5
+    fwd.check_flags()
