@@ -945,6 +945,24 @@ def graph_sage_edge_update_layer(node, edge, idx, p, act="relu", use_normalizati
     return ed
 
 
+def dmpnn_forward(params, node_attr, edge_attr, idx, reverse_pair, depth=5, pooling_method="sum",
+                  output_mlp_act=("relu", "relu", "linear")):
+    """``kgcnn.literature.DMPNN.make_model`` forward with feature inputs, ``output_embedding='graph'`` and inference-mode
+    dropout (kgcnn/literature/DMPNN.py:132-152).  ``params``: h0/, edge/, node/ {kernel,bias}, output_mlp/{k}/..."""
+    h_n0 = gather_nodes_outgoing(node_attr, idx)
+    h0 = dense(lazy_concatenate([h_n0, edge_attr], axis=-1), params["h0/kernel"], params.get("h0/bias"), "relu")
+    h = h0
+    for _ in range(depth):
+        m_vw = dmpnn_pooling_edges_directed(node_attr, h, idx, reverse_pair)
+        h = dense(m_vw, params["edge/kernel"], params.get("edge/bias"), "linear")
+        h = R(activation("relu", h.values + h0.values), h.row_splits)
+    mv = pooling_local_edges(node_attr, h, idx, pooling_method=pooling_method)
+    hv = dense(lazy_concatenate([mv, node_attr], axis=-1), params["node/kernel"], params.get("node/bias"), "relu")
+    out = pooling_nodes(hv, pooling_method=pooling_method)
+    return mlp(out, [(params["output_mlp/%d/kernel" % k], params.get("output_mlp/%d/bias" % k), output_mlp_act[k])
+                     for k in range(len(output_mlp_act))])
+
+
 def megnet_block(node, edge, idx, env, p, act="kgcnn>softplus2", pooling_method="mean"):
     """``MEGnetBlock.call``, kgcnn/layers/conv/megnet_conv.py:96-120.  ``env`` is a dense ``(G, Fu)`` array; ``p`` holds
     phi_e{,_1,_2}/phi_n{,_1,_2}/phi_u{,_1,_2} kernels and biases.  Returns ``(nodes, edges, env)``."""
