@@ -963,6 +963,29 @@ def dmpnn_forward(params, node_attr, edge_attr, idx, reverse_pair, depth=5, pool
                      for k in range(len(output_mlp_act))])
 
 
+def graphsage_forward(params, node_attr, edge_attr, idx, depth=3, use_edge_features=True, pooling_method="segment_mean",
+                      mlp_act=("relu", "linear"), pooling_nodes_method="mean", output_mlp_act=("relu", "relu", "sigmoid")):
+    """``kgcnn.literature.GraphSAGE.make_model`` forward with feature inputs and ``output_embedding='graph'``
+    (kgcnn/literature/GraphSAGE.py:103-123).  ``params``: block{i}/edge/{k}/{kernel,bias}, block{i}/node/{k}/...,
+    block{i}/norm/{gamma,beta}, output_mlp/{k}/..."""
+    n = node_attr
+    for i in range(depth):
+        eu = gather_nodes_outgoing(n, idx)
+        if use_edge_features:
+            eu = lazy_concatenate([eu, edge_attr], axis=-1)
+        eu = mlp(eu, [(params["block%d/edge/%d/kernel" % (i, k)], params.get("block%d/edge/%d/bias" % (i, k)), a)
+                      for k, a in enumerate(mlp_act)])
+        nu = pooling_local_edges(n, eu, idx, pooling_method=pooling_method)
+        nu = lazy_concatenate([n, nu], axis=-1)
+        n = mlp(nu, [(params["block%d/node/%d/kernel" % (i, k)], params.get("block%d/node/%d/bias" % (i, k)), a)
+                     for k, a in enumerate(mlp_act)])
+        n = R(layer_normalization(n.values, params["block%d/norm/gamma" % i], params["block%d/norm/beta" % i]),
+              n.row_splits)
+    out = pooling_nodes(n, pooling_method=pooling_nodes_method)
+    return mlp(out, [(params["output_mlp/%d/kernel" % k], params.get("output_mlp/%d/bias" % k), output_mlp_act[k])
+                     for k in range(len(output_mlp_act))])
+
+
 def megnet_block(node, edge, idx, env, p, act="kgcnn>softplus2", pooling_method="mean"):
     """``MEGnetBlock.call``, kgcnn/layers/conv/megnet_conv.py:96-120.  ``env`` is a dense ``(G, Fu)`` array; ``p`` holds
     phi_e{,_1,_2}/phi_n{,_1,_2}/phi_u{,_1,_2} kernels and biases.  Returns ``(nodes, edges, env)``."""

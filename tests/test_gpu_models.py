@@ -334,3 +334,46 @@ def test_dmpnn_builder_forward():
     assert np.max(np.abs(out - ref)) <= 2e-5 * max(1.0, np.max(np.abs(ref)))
     with pytest.raises(NotImplementedError):
         DMPNN.make_model(use_graph_state=True)
+
+
+def test_graphsage_builder_forward():
+    """``GraphSAGE.make_model`` (kgcnn/literature/GraphSAGE.py:95-135) with feature inputs vs the oracle."""
+    from gcnn_keras_amd.literature import GraphSAGE
+    from gcnn_keras_amd.ragged import RaggedTensor
+    b = synth.qm9_like_batch(num_graphs=6, seed=27)
+    rng = np.random.default_rng(28)
+    n, m = int(b["node_splits"][-1]), int(b["edge_splits"][-1])
+    fn, fe, depth = 10, 6, 2
+    x = rng.normal(size=(n, fn)).astype(np.float32)
+    e = rng.normal(size=(m, fe)).astype(np.float32)
+    model = GraphSAGE.make_model(
+        inputs=[{"shape": (None, fn), "name": "node_attributes", "dtype": "float32", "ragged": True},
+                {"shape": (None, fe), "name": "edge_attributes", "dtype": "float32", "ragged": True},
+                {"shape": (None, 2), "name": "edge_indices", "dtype": "int64", "ragged": True}],
+        node_mlp_args={"units": [24, 12]}, edge_mlp_args={"units": [20, 14]}, depth=depth)
+    p, arrays = {}, []
+    arrays += [w.cpu().numpy() for lay in model.layers[:2] for _, w in lay.weights]
+    def dense_pair(key, fin, fout, bias=True):
+        p[key + "/kernel"] = synth.glorot_uniform(rng, fin, fout)
+        arrays.append(p[key + "/kernel"])
+        if bias:
+            p[key + "/bias"] = (rng.normal(size=fout) * 0.1).astype(np.float32)
+            arrays.append(p[key + "/bias"])
+    width = fn
+    for i in range(depth):
+        dense_pair("block%d/edge/0" % i, width + fe, 20); dense_pair("block%d/edge/1" % i, 20, 14)
+        dense_pair("block%d/node/0" % i, width + 14, 24); dense_pair("block%d/node/1" % i, 24, 12)
+        p["block%d/norm/gamma" % i] = rng.uniform(0.5, 1.5, 12).astype(np.float32)
+        p["block%d/norm/beta" % i] = rng.normal(size=12).astype(np.float32)
+        arrays += [p["block%d/norm/gamma" % i], p["block%d/norm/beta" % i]]
+        width = 12
+    dense_pair("output_mlp/0", 12, 25); dense_pair("output_mlp/1", 25, 10); dense_pair("output_mlp/2", 10, 1, bias=False)
+    model.set_weights(arrays)
+    out = model([RaggedTensor.from_numpy(x, b["node_splits"]), RaggedTensor.from_numpy(e, b["edge_splits"]),
+                 RaggedTensor.from_numpy(b["edge_indices"], b["edge_splits"])]).cpu().numpy()
+    ref = ko.graphsage_forward(p, ko.R(x, b["node_splits"]), ko.R(e, b["edge_splits"]),
+                               ko.R(b["edge_indices"], b["edge_splits"]), depth=depth)
+    assert out.shape == (6, 1)
+    assert np.max(np.abs(out - ref)) <= 3e-5 * max(1.0, np.max(np.abs(ref)))
+    with pytest.raises(NotImplementedError):
+        GraphSAGE.make_model(pooling_args={"pooling_method": "LSTM"})
