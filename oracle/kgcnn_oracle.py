@@ -963,6 +963,27 @@ def dmpnn_forward(params, node_attr, edge_attr, idx, reverse_pair, depth=5, pool
                      for k in range(len(output_mlp_act))])
 
 
+def gin_forward(params, node_attr, idx, depth=3, gin_mlp_act=("relu", "linear"), last_mlp_act=("relu", "relu", "linear"),
+                output_act="softmax"):
+    """``kgcnn.literature.GIN.make_model`` forward with feature inputs, ``output_embedding='graph'``, no normalisation,
+    inference-mode dropout (kgcnn/literature/GIN.py:89-102).  ``params``: dense0/, gin{i}/eps, mlp{i}/{k}/,
+    last{j}/{k}/ (j = 0..depth), output/."""
+    n = dense(node_attr, params["dense0/kernel"], params.get("dense0/bias"), "linear")
+    embeddings = [n]
+    for i in range(depth):
+        n = gin_layer(n, idx, eps=params.get("gin%d/eps" % i, 0.0))
+        n = mlp(n, [(params["mlp%d/%d/kernel" % (i, k)], params.get("mlp%d/%d/bias" % (i, k)), a)
+                    for k, a in enumerate(gin_mlp_act)])
+        embeddings.append(n)
+    total = None
+    for j, x in enumerate(embeddings):
+        pooled = pooling_nodes(x, pooling_method="mean")
+        part = mlp(pooled, [(params["last%d/%d/kernel" % (j, k)], params.get("last%d/%d/bias" % (j, k)), a)
+                            for k, a in enumerate(last_mlp_act)])
+        total = part if total is None else total + part
+    return mlp(total, [(params["output/kernel"], params.get("output/bias"), output_act)])
+
+
 def graphsage_forward(params, node_attr, edge_attr, idx, depth=3, use_edge_features=True, pooling_method="segment_mean",
                       mlp_act=("relu", "linear"), pooling_nodes_method="mean", output_mlp_act=("relu", "relu", "sigmoid")):
     """``kgcnn.literature.GraphSAGE.make_model`` forward with feature inputs and ``output_embedding='graph'``

@@ -377,3 +377,41 @@ def test_graphsage_builder_forward():
     assert np.max(np.abs(out - ref)) <= 3e-5 * max(1.0, np.max(np.abs(ref)))
     with pytest.raises(NotImplementedError):
         GraphSAGE.make_model(pooling_args={"pooling_method": "LSTM"})
+
+
+def test_gin_builder_forward():
+    """``GIN.make_model`` (kgcnn/literature/GIN.py:82-116) with feature inputs, no normalisation, vs the oracle."""
+    from gcnn_keras_amd.literature import GIN
+    from gcnn_keras_amd.ragged import RaggedTensor
+    b = synth.qm9_like_batch(num_graphs=6, seed=29)
+    rng = np.random.default_rng(30)
+    n = int(b["node_splits"][-1])
+    fn, units, depth, classes = 9, 16, 2, 3
+    x = rng.normal(size=(n, fn)).astype(np.float32)
+    model = GIN.make_model(
+        inputs=[{"shape": (None, fn), "name": "node_attributes", "dtype": "float32", "ragged": True},
+                {"shape": (None, 2), "name": "edge_indices", "dtype": "int64", "ragged": True}],
+        gin_mlp={"units": [units, units]}, gin_args={"epsilon_learnable": True}, depth=depth,
+        last_mlp={"units": [12, 12, 8]}, output_mlp={"units": classes})
+    p, arrays = {}, []
+    arrays += [w.cpu().numpy() for _, w in model.layers[0].weights]
+    def dense_pair(key, fin, fout):
+        p[key + "/kernel"] = synth.glorot_uniform(rng, fin, fout)
+        p[key + "/bias"] = (rng.normal(size=fout) * 0.1).astype(np.float32)
+        arrays.extend([p[key + "/kernel"], p[key + "/bias"]])
+    dense_pair("dense0", fn, units)
+    for i in range(depth):
+        p["gin%d/eps" % i] = np.float32(0.1 * (i + 1))
+        arrays.append(p["gin%d/eps" % i])
+        dense_pair("mlp%d/0" % i, units, units); dense_pair("mlp%d/1" % i, units, units)
+    for j in range(depth + 1):
+        dense_pair("last%d/0" % j, units, 12); dense_pair("last%d/1" % j, 12, 12); dense_pair("last%d/2" % j, 12, 8)
+    dense_pair("output", 8, classes)
+    model.set_weights(arrays)
+    out = model([RaggedTensor.from_numpy(x, b["node_splits"]),
+                 RaggedTensor.from_numpy(b["edge_indices"], b["edge_splits"])]).cpu().numpy()
+    ref = ko.gin_forward(p, ko.R(x, b["node_splits"]), ko.R(b["edge_indices"], b["edge_splits"]), depth=depth)
+    assert out.shape == (6, classes) and np.allclose(out.sum(axis=1), 1.0, atol=1e-5)
+    assert np.max(np.abs(out - ref)) <= 2e-5
+    with pytest.raises(NotImplementedError):
+        GIN.make_model(gin_mlp={"use_normalization": True})
