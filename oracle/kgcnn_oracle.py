@@ -19,10 +19,11 @@ The oracle is pinned by the reference's own known answers (tests/test_oracle_pin
   4. test/test_geom.py:79-128 + test/assets/bessel_basis_reference.npz (copied as data to
      tests/golden/bessel_basis_reference.npz)  NodePosition -> NodeDistanceEuclidean ->
      BesselBasisLayer(10, 5.0)
+  5. test/test_conv_dmpnn.py:11-28    ``DMPNNGatherEdgesPairs`` on its two-graph fixture
 
 Everything else (PoolingLocalEdges sum/mean/max/min values, weighted pooling, PoolingNodes,
-SchNetCFconv / SchNetInteraction, PAiNNconv / PAiNNUpdate, GCN, Gaussian basis, whole-model
-outputs) is **parity unpinned** by the reference's own tests: those results are checked
+SchNetCFconv / SchNetInteraction, PAiNNconv / PAiNNUpdate, GCN, GIN, GAT heads, MEGNet block, GraphSAGE,
+layer normalisation, Gaussian basis, whole-model outputs) is **parity unpinned** by the reference's own tests: those results are checked
 against this restatement only, cross-checked by an independent torch-CPU formulation in
 tests/test_oracle_crosscheck.py.
 
