@@ -3,21 +3,31 @@
 
     python bench.py --gpus N --steps K --warmup W            (N > 1: launched by torch.distributed.run, one rank per GPU)
 
-A step = one SchNet forward (kgcnn.literature.Schnet.make_model, F=128, depth 3, Gauss(20, 4.0, 0.4), sum pooling)
-over one resident batch of BASELINE config 2 (128 QM9-shaped graphs, seed 1234 + rank): raw API inputs (float node
-numbers, float32 coordinates, int64 (M,2) sample indices, int64 row_splits) are in HBM when the clock starts; the index
-preparation (shift, CSR), geometry, basis expansion, every interaction block, readout and output MLP are inside it.
-Graphs shard by rank with no data-path collective (weak scaling: every rank owns its own 128-graph batch); the only
-collective is one all-gather of the (G,1) predictions per step (RCCL over xGMI), as BASELINE.json's north_star states.
+A step = one call ``model(inputs)`` of ``gcnn_keras_amd.literature.Schnet.make_model`` (the mirror of
+kgcnn.literature.Schnet.make_model: F=128, depth 3, Gauss(20, 4.0, 0.4), sum pooling) on a batch whose raw API inputs
+(float node numbers, float32 coordinates, int64 (M,2) sample indices, int64 row_splits) are resident in HBM when the
+clock starts; index preparation (shift, receiver/sender split), geometry, basis expansion, every interaction block,
+readout, output MLP and the copy of the (G,1) result into a fresh tensor are inside it.  The model routes such a call
+through its fused HIP kernels (8 launches, replayed from a HIP graph for a re-bound batch; gcnn_keras_amd/fused.py).
 
-One 128-graph forward cannot fill an MI355X (819 edge tiles for 1024 SIMDs, 144 node tiles for 256 CUs), so the loop keeps
-`--in-flight` (default 4) independent batch slots - own buffers, own HIP stream, own captured graph - busy: step i is one
-full forward of slot i % 4, launched with one hipGraphLaunch; kernels of different slots overlap on the GPU.  Exactly K
-forwards run inside the timed region.  `single_forward_latency_ms` reports the latency of a lone forward beside the
-throughput; `--in-flight 1` runs strictly one forward at a time.
+Workloads (``--workload``; default ``config2`` at N = 1 and ``config4`` at N > 1):
 
-Prints ONE JSON line (rank 0) with the contract keys plus `roofline` (dominant kernel, measured live with HIP events)
-and `cpu_baseline` (the NumPy oracle restating the reference's unfused TF op sequence, timed on the host cores).
+* ``config2``  BASELINE config 2, the configuration the metric is quoted on: 128 QM9-shaped graphs (seed 1234 + rank:
+  N=2301, M=26190 on rank 0).  One 128-graph forward cannot fill an MI355X (819 edge tiles for 1024 SIMDs, 144 node
+  tiles for 256 CUs), so the loop keeps ``--in-flight`` (default 4) independent batches - own tensors, own batch slot
+  inside the model, own HIP stream - busy: step i is one full ``model(inputs[i % 4])`` on stream i % 4; kernels of
+  different batches overlap on the GPU.  Exactly K forwards run inside the timed region; ``single_forward_latency_ms``
+  reports the latency of a lone forward beside the throughput.  With N > 1 (``--workload config2``) every rank owns its
+  own 128-graph batches and one all-gather of the (G,1) predictions follows every forward: weak scaling.
+* ``config4``  BASELINE config 4: 100 000 QM9-shaped molecules (seed 3456) cut into N contiguous shards balanced by edge
+  count (gcnn_keras_amd/sharding.py); rank r builds the edge lists of shard r on its GPU (the engine's SetRange, the
+  reference's rule), runs one forward per step on it - no exchange during the forward - and ONE RCCL all-gather returns
+  the (100000,1) predictions in graph order.  Total work is fixed as N grows: strong scaling.  At N = 1 the default run
+  appends this workload's single-GPU rate as ``config4_single_gpu`` (the N = 1 point of that curve).
+
+Prints ONE JSON line (rank 0) with the contract keys plus ``roofline`` (dominant kernel, measured live with HIP events)
+and ``cpu_baseline`` (CPU restatements of the reference's unfused op sequence - C/OpenMP port and torch-CPU - timed on
+the host cores).
 """
 import argparse
 import json
@@ -33,6 +43,7 @@ if ROOT not in sys.path:
 
 HBM_PEAK_GBS = 8000.0      # MI355X HBM3E spec (MI355X_MICROARCH.md chip table)
 FP32_MFMA_PEAK_TF = 157.3  # dense FP32 matrix peak (same table)
+DEPTH = 3
 
 
 def schnet_algorithmic_bytes(n, m, g, f=128, b=20, d=3):
@@ -46,43 +57,43 @@ def schnet_flops(n, m, g, f=128, b=20, d=3):
             + g * 2 * (64 * 64 + 64))
 
 
-def cpu_baseline(batch, params, depth, budget_s=12.0):
-    """The CPU port of the reference's unfused op sequence, timed on this host's cores; bounded to ~budget_s.
-    Prefers the C/OpenMP port (oracle/mp_oracle.c, all host cores); falls back to the NumPy oracle."""
-    from oracle import c_oracle
-    from oracle import kgcnn_oracle as ko
-    m = int(batch["edge_splits"][-1])
-    g = len(batch["node_splits"]) - 1
-    if c_oracle.available():
-        def run():
-            return c_oracle.schnet_forward(params, batch["node_number"], batch["node_coordinates"],
-                                           batch["edge_indices"], batch["node_splits"], batch["edge_splits"],
-                                           depth=depth)
-        cores, what = c_oracle.num_threads(), "C/OpenMP port oracle/mp_oracle.c"
-    else:
-        inputs = (ko.R(batch["node_number"], batch["node_splits"]),
-                  ko.R(batch["node_coordinates"], batch["node_splits"]),
-                  ko.R(batch["edge_indices"], batch["edge_splits"]))
-
-        def run():
-            return ko.schnet_forward(params, *inputs, depth=depth)
-        try:
-            import threadpoolctl
-            cores = max([p.get("num_threads", 1) for p in threadpoolctl.threadpool_info()] or [1])
-        except Exception:  # pragma: no cover
-            cores = os.cpu_count() or 1
-        what = "NumPy oracle (BLAS sgemm threaded, gather / segment ops single-threaded)"
+def _timed(run, budget_s, max_runs=200):
     run()  # warm-up
     times = []
     t_end = time.perf_counter() + budget_s
-    while time.perf_counter() < t_end and len(times) < 200:
+    while time.perf_counter() < t_end and len(times) < max_runs:
         t0 = time.perf_counter()
         run()
         times.append(time.perf_counter() - t0)
-    med = float(np.median(times))
-    return {"value": m / med, "unit": "edges/s", "cores": int(cores), "kind": "port",
-            "sample": "%d forwards of the same %d-graph batch (median %.1f ms) with the %s on %d threads"
-                      % (len(times), g, med * 1e3, what, int(cores))}
+    return float(np.median(times)), len(times)
+
+
+def cpu_baseline(batch, params, depth, budget_s=8.0):
+    """CPU restatements of the reference's unfused op sequence on this host's cores, ~budget_s each (BASELINE.md
+    section 2): (i) the C/OpenMP port oracle/mp_oracle.c, (ii) torch-CPU (index_select / index_add_ / addmm).  ``value``
+    is the faster of the two; both are listed."""
+    from oracle import c_oracle, torch_oracle
+    import torch
+    m = int(batch["edge_splits"][-1])
+    g = len(batch["node_splits"]) - 1
+    legs = {}
+    if c_oracle.available():
+        med, runs = _timed(lambda: c_oracle.schnet_forward(params, batch["node_number"], batch["node_coordinates"],
+                                                           batch["edge_indices"], batch["node_splits"],
+                                                           batch["edge_splits"], depth=depth), budget_s)
+        legs["c_openmp"] = {"value": m / med, "median_ms": med * 1e3, "forwards": runs,
+                            "threads": c_oracle.num_threads(), "what": "C/OpenMP port oracle/mp_oracle.c"}
+    tp, tb = torch_oracle.to_torch(params), torch_oracle.prepare(batch)
+    med, runs = _timed(lambda: torch_oracle.schnet_forward(tp, tb, depth=depth), budget_s)
+    legs["torch_cpu"] = {"value": m / med, "median_ms": med * 1e3, "forwards": runs,
+                         "threads": int(torch.get_num_threads()),
+                         "what": "torch-CPU restatement oracle/torch_oracle.py (index_select / index_add_ / addmm)"}
+    best = max(legs, key=lambda k: legs[k]["value"])
+    return {"value": legs[best]["value"], "unit": "edges/s", "cores": int(legs[best]["threads"]), "kind": "port",
+            "sample": "%d forwards of the same %d-graph batch (median %.1f ms) with the %s on %d threads; host has %d "
+                      "logical cores" % (legs[best]["forwards"], g, legs[best]["median_ms"], legs[best]["what"],
+                                         legs[best]["threads"], os.cpu_count() or 0),
+            "legs": legs}
 
 
 def pmc_traffic(kernel_name, graphs):
@@ -106,17 +117,249 @@ def pmc_traffic(kernel_name, graphs):
     return {"traffic": None}
 
 
+class _Dist:
+    """torch.distributed plumbing of one rank (RCCL = backend "nccl"; gloo only rehearses N > 1 on a one-GPU box)."""
+
+    def __init__(self, args):
+        import torch
+        self.torch = torch
+        self.rank = int(os.environ.get("RANK", "0"))
+        self.local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+        self.world = int(os.environ.get("WORLD_SIZE", "1"))
+        if self.world != args.gpus:
+            raise SystemExit("--gpus %d but WORLD_SIZE=%d: launch with torch.distributed.run --nproc-per-node %d"
+                             % (args.gpus, self.world, args.gpus))
+        ndev = torch.cuda.device_count()
+        self.device_index = self.local_rank % max(ndev, 1)  # one rank per GPU; wraps only in one-GPU rehearsals
+        torch.cuda.set_device(self.device_index)
+        self.backend = args.backend
+        self.dist = None
+        if self.world > 1:
+            import torch.distributed as dist
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            if self.backend == "nccl":
+                dist.init_process_group("nccl", rank=self.rank, world_size=self.world,
+                                        device_id=torch.device("cuda", self.device_index))
+            else:
+                dist.init_process_group("gloo", rank=self.rank, world_size=self.world)
+            self.dist = dist
+
+    def barrier(self):
+        self.torch.cuda.synchronize()
+        if self.dist is not None:
+            self.dist.barrier()
+        self.torch.cuda.synchronize()
+
+    def reduce(self, value, op):
+        t = self.torch.tensor([value], dtype=self.torch.float64,
+                              device="cuda" if (self.backend == "nccl" or self.world == 1) else "cpu")
+        if self.dist is not None:
+            self.dist.all_reduce(t, op=getattr(self.dist.ReduceOp, op))
+        return float(t.item())
+
+    def close(self):
+        if self.dist is not None:
+            self.dist.destroy_process_group()
+
+
+def _time_steps(d, step, warmup, steps):
+    """W untimed warm-up steps, then exactly K steps bracketed by barrier + synchronize; MAX over ranks."""
+    torch = d.torch
+    for i in range(warmup):
+        step(i)
+    d.barrier()
+    t0 = time.perf_counter()
+    for i in range(steps):
+        step(i)
+    torch.cuda.set_stream(torch.cuda.default_stream())
+    d.barrier()
+    return d.reduce(time.perf_counter() - t0, "MAX")
+
+
+# ---------------------------------------------------------------------------------------------------- config 2
+def run_config2(args, d):
+    torch = d.torch
+    from gcnn_keras_amd import synth
+    from gcnn_keras_amd.engine import SchnetForward
+    world = d.world
+    batch = synth.qm9_like_batch(num_graphs=args.graphs, seed=1234 + d.rank)
+    params = synth.schnet_params(seed=7)  # Keras defaults: glorot_uniform kernels, zero biases, U(-0.05, 0.05) embedding
+    n_nodes, n_edges, n_graphs = int(batch["node_splits"][-1]), int(batch["edge_splits"][-1]), args.graphs
+
+    fwd = SchnetForward(params, depth=DEPTH, mode=args.mode, in_flight=args.in_flight)
+    fwd.load_batch(batch)
+    slots = fwd.in_flight
+    gathered = [torch.empty((world * n_graphs, 1), dtype=torch.float32, device="cuda") for _ in range(slots)] \
+        if world > 1 else None
+    host_parts = [torch.empty((n_graphs, 1)) for _ in range(world)] if (world > 1 and d.backend == "gloo") else None
+
+    def step(i):
+        # one model(inputs) call on the batch's stream; with RCCL the all-gather is ordered after it on that stream
+        # (the process group serialises the collectives of different slots in issue order)
+        if world == 1:
+            return fwd.replay(i)
+        with torch.cuda.stream(fwd.stream_of(i)):
+            out = fwd.forward(i)
+            if host_parts is None:
+                d.dist.all_gather_into_tensor(gathered[i % slots], out)
+            else:
+                d.dist.all_gather(host_parts, out.cpu())                # rehearsal only
+        return out
+
+    elapsed = _time_steps(d, step, args.warmup, args.steps)
+    total_edges = d.reduce(float(n_edges), "SUM")
+    fwd.check_flags()
+    # latency of ONE model(inputs) call with nothing else on the GPU (batch 0 alone), beside the throughput
+    for _ in range(10):
+        fwd.replay(0)
+    torch.cuda.synchronize()
+    t1 = time.perf_counter()
+    for _ in range(100):
+        fwd.replay(0)
+    torch.cuda.synchronize()
+    latency_ms = (time.perf_counter() - t1) / 100 * 1e3
+    roof = fwd.roofline(HBM_PEAK_GBS, FP32_MFMA_PEAK_TF)  # dominant kernel, timed with HIP events on its stream
+    roof.update(pmc_traffic(roof.get("kernel", ""), n_graphs))
+    roof["measured"] = ("HIP events on the kernel's stream around back-to-back launches of the kernel alone on the GPU, "
+                        "after the timed region; rocprofv3 --kernel-trace --stats of `bench.py --in-flight 1` "
+                        "(profiles/) gives the same average; with batches in flight kernels of different batches share "
+                        "CUs and their individual durations stretch")
+    if d.rank != 0:
+        return None
+    ms_per_step = elapsed / args.steps * 1e3
+    fwd_bytes = schnet_algorithmic_bytes(n_nodes, n_edges, n_graphs, d=DEPTH)
+    fwd_flops = schnet_flops(n_nodes, n_edges, n_graphs, d=DEPTH)
+    line = {
+        "metric": "edges/sec (SchNet fwd, QM9-shape batch)", "value": total_edges * args.steps / elapsed,
+        "unit": "edges/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": "BASELINE config 2: Schnet.make_model forward (F=128, depth 3, Gauss 20) on %d QM9-shaped "
+                               "graphs per GPU, N=%d nodes, M=%d directed edges on rank 0"
+                               % (n_graphs, n_nodes, n_edges),
+                   "graphs_per_gpu": n_graphs, "nodes": n_nodes, "edges": n_edges, "mode": fwd.mode,
+                   "in_flight": slots, "api": "gcnn_keras_amd.literature.Schnet.make_model(depth=3)(inputs)",
+                   "step": "one model(inputs) call on one batch; %d independent batches (own tensors, batch slot and HIP "
+                           "stream) are in flight, so kernels of different batches share the GPU" % slots,
+                   "sharding": "by graph, 1 all-gather of predictions per step" if world > 1 else "single GPU"},
+        "single_forward_latency_ms": latency_ms,
+        "roofline": roof,
+        "forward_model": {"hbm_frac": fwd_bytes / (ms_per_step * 1e-3) / (HBM_PEAK_GBS * 1e9),
+                          "mfma_frac": fwd_flops / (ms_per_step * 1e-3) / (FP32_MFMA_PEAK_TF * 1e12),
+                          "algorithmic_bytes": fwd_bytes, "flops": fwd_flops,
+                          "kernels_per_forward": fwd.num_launches},
+    }
+    if world == 1 and not args.no_cpu_baseline:
+        line["cpu_baseline"] = cpu_baseline(batch, params, DEPTH)
+    if fwd.model.fused is not None:
+        fwd.model.fused.release()
+    return line
+
+
+# ---------------------------------------------------------------------------------------------------- config 4
+def build_config4_shard(total_graphs, rank, world, seed=3456):
+    """Rank ``rank``'s shard of the 100 000-molecule workload as resident ragged inputs + the shard bounds of all ranks.
+    Node data come from the seeded host generator; edge counts (for the balance) and the shard's edge lists are made on
+    the GPU by the engine's SetRange with config 2's rule (max_distance 4, max_neighbours 30)."""
+    import torch
+    from gcnn_keras_amd import sharding, synth
+    from gcnn_keras_amd.graph.preprocessor import SetRange
+    from gcnn_keras_amd.ragged import RaggedTensor
+    nodes = synth.qm9_like_nodes(total_graphs, seed=seed)
+    rule = SetRange(max_distance=4.0, max_neighbours=30)
+    all_xyz = RaggedTensor.from_numpy(nodes["node_coordinates"], nodes["node_splits"])
+    edge_splits = rule.count_edges(all_xyz).cpu().numpy()
+    del all_xyz
+    bounds = sharding.shard_bounds_by_edges(edge_splits, world)
+    lo, hi = bounds[rank]
+    ns = nodes["node_splits"]
+    n0, n1 = int(ns[lo]), int(ns[hi])
+    splits = (ns[lo:hi + 1] - n0).astype(np.int64)
+    z = RaggedTensor.from_numpy(nodes["node_number"][n0:n1], splits)
+    xyz = RaggedTensor.from_numpy(nodes["node_coordinates"][n0:n1], splits)
+    xyz.row_splits = z.row_splits  # one partition tensor for both node properties, as a RaggedTensor batch has
+    idx, _ = rule(xyz)   # carries a ready index plan: receiver-sorted, range-checked by construction
+    torch.cuda.synchronize()
+    return [z, xyz, idx], bounds, int(edge_splits[-1])
+
+
+def run_config4(args, d, standalone=True):
+    torch = d.torch
+    from gcnn_keras_amd import sharding, synth
+    from gcnn_keras_amd.literature import Schnet
+    world = d.world
+    inputs, bounds, total_edges = build_config4_shard(args.total_graphs, d.rank, world)
+    n_nodes, n_edges, n_graphs = int(inputs[0].values.shape[0]), int(inputs[2].values.shape[0]), inputs[0].nrows()
+    params = synth.schnet_params(seed=7)
+    model = Schnet.make_model(depth=DEPTH)
+    model.set_weights(list(params.values()))
+    if model.fused is None or not model.fused.accepts(inputs):
+        raise SystemExit("config 4 expects the fused route")
+    gloo = world > 1 and d.backend == "gloo"
+
+    def step(i):
+        pred = model(inputs)                               # one forward of this rank's shard, no exchange inside
+        if world > 1:
+            pred = sharding.all_gather_predictions(pred.cpu() if gloo else pred, bounds)   # (total_graphs, 1)
+        return pred
+
+    steps, warmup = args.steps, args.warmup
+    if not standalone:
+        steps, warmup = 10, 3
+    elapsed = _time_steps(d, step, warmup, steps)
+    model.fused.check_flags()
+    full = step(0)
+    torch.cuda.synchronize()
+    assert tuple(full.shape) == (args.total_graphs, 1) and bool(torch.isfinite(full).all())
+    slot = model.fused.slot_of(inputs)
+    roof = slot.roofline(HBM_PEAK_GBS, FP32_MFMA_PEAK_TF, iters=10)
+    roof["measured"] = "HIP events on the kernel's stream around back-to-back launches of the kernel alone, after the timed region"
+    model.fused.release()
+    if d.rank != 0:
+        return None
+    ms_per_step = elapsed / steps * 1e3
+    fwd_flops = schnet_flops(n_nodes, n_edges, n_graphs, d=DEPTH)
+    fwd_bytes = schnet_algorithmic_bytes(n_nodes, n_edges, n_graphs, d=DEPTH)
+    line = {
+        "metric": "edges/sec (SchNet fwd, QM9-shape batch)", "value": total_edges * steps / elapsed,
+        "unit": "edges/s", "n_gpus": world, "steps": steps, "warmup": warmup, "ms_per_step": ms_per_step,
+        "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": "BASELINE config 4: Schnet.make_model forward (F=128, depth 3, Gauss 20) on %d QM9-shaped "
+                               "molecules (seed 3456, %d directed edges) sharded by graph over %d GPU(s), balanced by edge "
+                               "count; one forward per shard and step, one all-gather of the (%d,1) predictions"
+                               % (args.total_graphs, total_edges, world, args.total_graphs),
+                   "total_graphs": args.total_graphs, "total_edges": total_edges,
+                   "rank0_shard": {"graphs": n_graphs, "nodes": n_nodes, "edges": n_edges},
+                   "api": "gcnn_keras_amd.literature.Schnet.make_model(depth=3)(inputs)",
+                   "sharding": ("contiguous graph ranges by edge count, no exchange during the forward, 1 "
+                                "all_gather_into_tensor per step (RCCL)" if world > 1 else "single GPU, no collective")},
+        "roofline": roof,
+        "forward_model": {"hbm_frac": fwd_bytes / (ms_per_step * 1e-3) / (HBM_PEAK_GBS * 1e9),
+                          "mfma_frac": fwd_flops / (ms_per_step * 1e-3) / (FP32_MFMA_PEAK_TF * 1e12),
+                          "algorithmic_bytes_rank0": fwd_bytes, "flops_rank0": fwd_flops},
+    }
+    if standalone and world == 1 and not args.no_cpu_baseline:
+        sample = synth.qm9_like_batch(num_graphs=128, seed=3456)   # the first 128 molecules of the same stream
+        line["cpu_baseline"] = cpu_baseline(sample, params, DEPTH)
+    return line
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
-    ap.add_argument("--graphs", type=int, default=128, help="graphs per GPU (BASELINE config 2 = 128)")
+    ap.add_argument("--workload", default="auto", choices=["auto", "config2", "config4"],
+                    help="auto: config2 at 1 GPU (the configuration the metric is quoted on), config4 (100 000 molecules "
+                         "sharded by graph + one all-gather) at N > 1")
+    ap.add_argument("--graphs", type=int, default=128, help="config2: graphs per GPU (BASELINE config 2 = 128)")
+    ap.add_argument("--total-graphs", type=int, default=100000, help="config4: molecules in the whole job")
     ap.add_argument("--mode", default="auto", choices=["auto", "fused", "layers"])
     ap.add_argument("--in-flight", type=int, default=4,
-                    help="independent batch slots (own buffers + HIP stream + graph) whose forwards overlap on the GPU; "
-                         "1 = strictly one forward at a time")
+                    help="config2: independent batches (own tensors + batch slot + HIP stream) whose forwards overlap on "
+                         "the GPU; 1 = strictly one forward at a time")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-config4-reference", action="store_true",
+                    help="skip the single-GPU config-4 rate appended to the default 1-GPU line")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="nccl = RCCL over xGMI (production); gloo only rehearses N > 1 on a single-GPU box")
     args = ap.parse_args()
@@ -125,124 +368,22 @@ def main():
     # hardware queues; 8 instead of the default 4 leave room beside the null stream, and SchnetForward.load_batch picks
     # the best of a few stream draws (engine.py:_place_streams).  Must be set before the HIP runtime initialises.
     os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
-    import torch
-    from gcnn_keras_amd import synth
-    from gcnn_keras_amd.engine import SchnetForward
-
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world != args.gpus:
-        raise SystemExit("--gpus %d but WORLD_SIZE=%d: launch with torch.distributed.run --nproc-per-node %d"
-                         % (args.gpus, world, args.gpus))
-    ndev = torch.cuda.device_count()
-    device_index = local_rank % max(ndev, 1)  # one rank per GPU on a full node; wraps only in single-GPU rehearsals
-    torch.cuda.set_device(device_index)
-    dist = None
-    if world > 1:
-        import torch.distributed as dist
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        if args.backend == "nccl":
-            dist.init_process_group("nccl", rank=rank, world_size=world,
-                                    device_id=torch.device("cuda", device_index))
-        else:
-            dist.init_process_group("gloo", rank=rank, world_size=world)
-
-    depth = 3
-    batch = synth.qm9_like_batch(num_graphs=args.graphs, seed=1234 + rank)
-    params = synth.schnet_params(seed=7)  # Keras defaults: glorot_uniform kernels, zero biases, U(-0.05, 0.05) embedding
-    n_nodes, n_edges, n_graphs = int(batch["node_splits"][-1]), int(batch["edge_splits"][-1]), args.graphs
-
-    fwd = SchnetForward(params, depth=depth, mode=args.mode, in_flight=args.in_flight)
-    fwd.load_batch(batch)
-    slots = fwd.in_flight
-    gathered = [torch.empty((world * n_graphs, 1), dtype=torch.float32, device="cuda") for _ in range(slots)] \
-        if world > 1 else None
-
-    host_parts = [torch.empty((n_graphs, 1)) for _ in range(world)] if (world > 1 and args.backend == "gloo") else None
-
-    def step(i):
-        # one forward of one batch on its slot's stream; with RCCL the all-gather is ordered after it on that stream
-        # (the process group serialises the collectives of different slots in issue order)
-        if world == 1:
-            return fwd.replay(i)                                       # one C-ABI call: hipGraphLaunch on the slot's stream
-        torch.cuda.set_stream(fwd.stream_of(i))                        # cheaper than a stream context per step
-        out = fwd.replay(i)
-        if host_parts is None:
-            dist.all_gather_into_tensor(gathered[i % slots], out)
-        else:
-            dist.all_gather(host_parts, out.cpu())                     # rehearsal only
-        return out
-
-    def reduce_scalar(value, op):
-        t = torch.tensor([value], dtype=torch.float64, device="cuda" if args.backend == "nccl" else "cpu")
-        if world > 1:
-            dist.all_reduce(t, op=op)
-        return float(t.item())
-
-    for i in range(args.warmup):
-        step(i)
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for i in range(args.steps):
-        step(i)
-    torch.cuda.set_stream(torch.cuda.default_stream())
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    elapsed = time.perf_counter() - t0
-    elapsed = reduce_scalar(elapsed, dist.ReduceOp.MAX if world > 1 else None)
-    total_edges = reduce_scalar(float(n_edges), dist.ReduceOp.SUM if world > 1 else None)
-
-    fwd.check_flags()
-    # latency of ONE forward with nothing else on the GPU (slot 0 alone), for reference beside the throughput
-    with torch.cuda.stream(fwd.stream_of(0)):
-        for _ in range(10):
-            fwd.replay(0)
-        torch.cuda.synchronize()
-        t1 = time.perf_counter()
-        for _ in range(100):
-            fwd.replay(0)
-        torch.cuda.synchronize()
-    latency_ms = (time.perf_counter() - t1) / 100 * 1e3
-    roof = fwd.roofline(HBM_PEAK_GBS, FP32_MFMA_PEAK_TF)  # dominant kernel, timed with HIP events on its stream
-    roof.update(pmc_traffic(roof.get("kernel", ""), n_graphs))
-    roof["measured"] = ("HIP events on the kernel's stream around back-to-back launches of the kernel alone on the GPU, after "
-                        "the timed region; rocprofv3 of `bench.py --in-flight 1` (profiles/r01_fused_config2_kernel_stats.csv) "
-                        "gives the same average; with batches in flight kernels of different batches share CUs and their "
-                        "individual durations stretch (profiles/r01_fused_config2_inflight4_kernel_stats.csv)")
-
-    if rank == 0:
-        ms_per_step = elapsed / args.steps * 1e3
-        value = total_edges * args.steps / elapsed
-        fwd_bytes = schnet_algorithmic_bytes(n_nodes, n_edges, n_graphs, d=depth)
-        fwd_flops = schnet_flops(n_nodes, n_edges, n_graphs, d=depth)
-        line = {
-            "metric": "edges/sec (SchNet fwd, QM9-shape batch)", "value": value, "unit": "edges/s",
-            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "BASELINE config 2: SchNet forward (F=128, depth 3, Gauss 20) on %d QM9-shaped graphs "
-                                   "per GPU, N=%d nodes, M=%d directed edges on rank 0" % (n_graphs, n_nodes, n_edges),
-                       "graphs_per_gpu": n_graphs, "nodes": n_nodes, "edges": n_edges, "mode": fwd.mode,
-                       "in_flight": slots,
-                       "step": "one forward of one batch; %d independent batch slots (own buffers, HIP stream and "
-                               "graph) are in flight, so kernels of different batches share the GPU" % slots,
-                       "sharding": "by graph, 1 all-gather of predictions per step" if world > 1 else "single GPU"},
-            "single_forward_latency_ms": latency_ms,
-            "roofline": roof,
-            "forward_model": {"hbm_frac": fwd_bytes / (ms_per_step * 1e-3) / (HBM_PEAK_GBS * 1e9),
-                              "mfma_frac": fwd_flops / (ms_per_step * 1e-3) / (FP32_MFMA_PEAK_TF * 1e12),
-                              "algorithmic_bytes": fwd_bytes, "flops": fwd_flops, "kernels_per_forward": fwd.num_launches},
-        }
-        if world == 1 and not args.no_cpu_baseline:
-            line["cpu_baseline"] = cpu_baseline(batch, params, depth)
+    d = _Dist(args)
+    workload = args.workload
+    if workload == "auto":
+        workload = "config2" if d.world == 1 else "config4"
+    if workload == "config2":
+        line = run_config2(args, d)
+        if line is not None and d.world == 1 and args.workload == "auto" and not args.no_config4_reference:
+            ref = run_config4(args, d, standalone=False)
+            line["config4_single_gpu"] = {k: ref[k] for k in ("value", "unit", "ms_per_step", "steps", "scaling")}
+            line["config4_single_gpu"]["workload"] = ref["config"]["workload"]
+            line["config4_single_gpu"]["cfconv_tflops"] = ref["roofline"]["achieved"]
+    else:
+        line = run_config4(args, d)
+    if d.rank == 0:
         print(json.dumps(line))
-    if world > 1:
-        dist.destroy_process_group()
+    d.close()
 
 
 if __name__ == "__main__":

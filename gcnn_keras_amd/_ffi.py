@@ -69,8 +69,14 @@ _SIGNATURES = {
     "mp_cfconv_pack_f32": [P, P, c_int, P, P, P, P],
     "mp_cfconv_fused_f32": [P, c_int64, P, c_int, P, P, P, P, c_int64, c_int, P, P],
     "mp_cfconv_gauss_fused_f32": [P, c_int64, P, c_int, c_float, c_float, c_float, P, P, P, P, c_int64, c_int, P, P],
+    "mp_cfconv_det_workspace_bytes": [c_int64, P],
+    "mp_cfconv_fused_ws_f32": [P, c_int64, P, c_int, P, P, P, P, c_int64, c_int, P, P, c_size_t, P],
+    "mp_cfconv_gauss_fused_ws_f32": [P, c_int64, P, c_int, c_float, c_float, c_float, P, P, P, P, c_int64, c_int, P, P,
+                                     c_size_t, P],
     "mp_cfconv_gauss_diag_f32": [P, c_int64, P, c_int, c_float, c_float, c_float, P, P, P, P, c_int64, P, P, P],
     "mp_painn_message_fused_f32": [P, P, c_int64, P, c_int, P, P, P, P, P, P, P, c_int64, P, P, P],
+    "mp_schnet_node_pack_f32": [P, c_int, c_int, P, P],
+    "mp_schnet_node_residual_f32": [P, c_int64, P, P, P, P, P, P, c_int, P],
     "mp_schnet_node_in_f32": [P, c_int64, P, c_int, c_int, P, P, P, P, P, c_int, P],
     "mp_schnet_stage0_f32": [P, c_int64, P, c_int, c_int, P, P, P, P, P, P, c_int64, P, P, c_int64, P, P, P, P, P, c_int,
                              P],

@@ -40,6 +40,8 @@
 //    non-matrix phases are written for instruction count (packed FP32, scalar control, 6-instruction softplus).
 //  * The output buffer must be zero on entry (unconnected nodes keep 0 = the has_unconnected pad of
 //    kgcnn/layers/pooling.py:74-76).
+#include <mutex>
+
 #include "mp_common.h"
 
 namespace {
@@ -80,6 +82,11 @@ struct CfconvArgs {
   int B;
   float g_distance, g_gamma, g_offset;  // Gauss basis parameters (geom.py:567-571)
   int ntiles;
+  // deterministic mode (flags bit 5): the partial sums of a tile's first and last segment - which may continue in the
+  // neighbouring tiles - are not added to `out` with float atomics but stored to bnd_val[2 tile + {0,1}][F] with their
+  // receiver in bnd_node[...] (-1 = none); cfconv_boundary_kernel then adds them per receiver in tile order.
+  float* bnd_val;
+  int32_t* bnd_node;
   unsigned long long* diag;  // optional [8] cycle sums per phase (diagnostic build only)
 };
 
@@ -356,7 +363,13 @@ __global__ __launch_bounds__(WAVES * 64, (WAVES == 4 && COMPACT) ? 2 : 1) void c
     // 4c..4c+3 are first transposed through 512 B of LDS so that each of the four atomic instructions of a half wave
     // covers ONE contiguous line (features 32 jb + c) instead of four (measured: 3.3 us -> <1 us per launch at config 2).
     float* const xs_half = Xs + (wave * 2 + hh) * F;
-    auto atomic_row = [&](int node, float v0, float v1, float v2, float v3) {
+    auto atomic_row = [&](int node, int which, float v0, float v1, float v2, float v3) {
+      if (a.bnd_val != nullptr) {  // deterministic mode: park the partial row, slot `which` (0 = tile's first segment)
+        const int64_t slot = 2 * static_cast<int64_t>(tile) + which;
+        *reinterpret_cast<float4*>(a.bnd_val + slot * F + 4 * c) = make_float4(v0, v1, v2, v3);
+        if (c == 0) a.bnd_node[slot] = node;
+        return;
+      }
       *reinterpret_cast<float4*>(xs_half + 4 * c) = make_float4(v0, v1, v2, v3);
       float* dst = a.out + static_cast<int64_t>(node) * F + c;
 #pragma unroll
@@ -372,9 +385,9 @@ __global__ __launch_bounds__(WAVES * 64, (WAVES == 4 && COMPACT) ? 2 : 1) void c
     }
     MP_STAMP(6)
     if (hh == 0) {
-      if (nlo > 1) atomic_row(node_e0, first[0], first[1], first[2], first[3]);  // first segment closed in the low half
+      if (nlo > 1) atomic_row(node_e0, 0, first[0], first[1], first[2], first[3]);  // first segment closed in the low half
       if (!cont) {    // the low half's last segment ends at edge 15
-        if (nlo == 1) atomic_row(node_e15, acc[0], acc[1], acc[2], acc[3]);      // it is also the tile's first
+        if (nlo == 1) atomic_row(node_e15, 0, acc[0], acc[1], acc[2], acc[3]);      // it is also the tile's first
         else store_row(node_e15, acc[0], acc[1], acc[2], acc[3]);
       }
     } else {
@@ -385,9 +398,10 @@ __global__ __launch_bounds__(WAVES * 64, (WAVES == 4 && COMPACT) ? 2 : 1) void c
         const float mine = nhi > 1 ? first[jb] : acc[jb];
         v0[jb] = cont ? tail[jb] + mine : mine;   // edge order: low-half part first
       }
-      if ((cont && nlo == 1) || nhi == 1) atomic_row(node_e16, v0[0], v0[1], v0[2], v0[3]);  // tile's first or last edge
+      // tile's first segment (it reaches back to edge 0) or its last one (it reaches edge 31) - or the whole tile
+      if ((cont && nlo == 1) || nhi == 1) atomic_row(node_e16, (cont && nlo == 1) ? 0 : 1, v0[0], v0[1], v0[2], v0[3]);
       else store_row(node_e16, v0[0], v0[1], v0[2], v0[3]);
-      if (nhi > 1) atomic_row(node_e31, acc[0], acc[1], acc[2], acc[3]);                     // the tile's last segment
+      if (nhi > 1) atomic_row(node_e31, 1, acc[0], acc[1], acc[2], acc[3]);                  // the tile's last segment
     }
     MP_STAMP(7)
   }
@@ -426,6 +440,49 @@ __global__ void cfconv_pack_kernel(const float* __restrict__ W1, const float* __
   }
 }
 
+// Deterministic mode, second pass.  Slot 2t holds tile t's first-segment partial (always present: the first segment
+// touches the tile start), slot 2t+1 its last-segment partial if the tile has more than one segment.  Receivers are
+// sorted, so the slots that belong to one receiver are consecutive; the first of them (the leader) sums the run in slot
+// order - i.e. in edge order - and stores the row: nothing else writes that receiver (a receiver gets either plain
+// stores, when its segment is interior to one tile, or boundary partials, never both), so the result does not depend on
+// scheduling.  One 32-lane group per slot, lane = four features.
+__global__ void cfconv_boundary_kernel(const float* __restrict__ bnd_val, const int32_t* __restrict__ bnd_node,
+                                       int64_t nslots, float* __restrict__ out) {
+  const int64_t group = (static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x) >> 5;
+  const int64_t ngroups = (static_cast<int64_t>(gridDim.x) * blockDim.x) >> 5;
+  const int c = threadIdx.x & 31;
+  for (int64_t i = group; i < nslots; i += ngroups) {
+    const int node = bnd_node[i];
+    if (node < 0) continue;
+    if (i > 0) {  // previous occupied slot: i-1 if occupied, else i-2 (even slots are always occupied)
+      int prev = bnd_node[i - 1];
+      if (prev < 0 && i > 1) prev = bnd_node[i - 2];
+      if (prev == node) continue;  // not the leader of its run
+    }
+    float4 sum = reinterpret_cast<const float4*>(bnd_val + i * F)[c];
+    for (int64_t j = i + 1; j < nslots; ++j) {
+      const int nj = bnd_node[j];
+      if (nj < 0) continue;
+      if (nj != node) break;
+      const float4 v = reinterpret_cast<const float4*>(bnd_val + j * F)[c];
+      sum.x += v.x; sum.y += v.y; sum.z += v.z; sum.w += v.w;
+    }
+    reinterpret_cast<float4*>(out + static_cast<int64_t>(node) * F)[c] = sum;
+  }
+}
+
+// hipFuncSetAttribute(MaxDynamicSharedMemorySize) is per device and per kernel: remember, under a mutex, on which
+// devices each instantiation has been opted in (a process may drive several GPUs, from several threads).
+inline int ensure_dynamic_lds(const void* kernel, size_t lds, unsigned long long* done_mask, std::mutex* mu) {
+  int dev = 0;
+  MP_HIP(hipGetDevice(&dev));
+  std::lock_guard<std::mutex> lock(*mu);
+  if (dev < 64 && ((*done_mask >> dev) & 1ull)) return MP_OK;
+  MP_HIP(hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds)));
+  if (dev < 64) *done_mask |= 1ull << dev;
+  return MP_OK;
+}
+
 template <int WAVES, int NKT>
 size_t cfconv_lds_bytes() {
   return sizeof(float) * ((NKT > 0 ? 2 * NKT : MAX_KROWS) * F + F * F + WAVES * 2 * F);
@@ -434,13 +491,11 @@ size_t cfconv_lds_bytes() {
 template <int WAVES, bool GAUSS, bool FAST, int NKT, bool DIAG, bool COMPACT = false>
 int launch_cfconv(const CfconvArgs& args, int grid, hipStream_t s) {
   const size_t lds = cfconv_lds_bytes<WAVES, NKT>();
-  static bool attr_set = false;
-  if (!attr_set) {
-    MP_HIP(hipFuncSetAttribute(
-        reinterpret_cast<const void*>(&cfconv_fused_kernel<WAVES, GAUSS, FAST, NKT, DIAG, COMPACT>),
-        hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds)));
-    attr_set = true;
-  }
+  static std::mutex mu;                    // one per instantiation, like the mask: guarded, per device
+  static unsigned long long done_mask = 0;
+  const int rc = ensure_dynamic_lds(
+      reinterpret_cast<const void*>(&cfconv_fused_kernel<WAVES, GAUSS, FAST, NKT, DIAG, COMPACT>), lds, &done_mask, &mu);
+  if (rc != MP_OK) return rc;
   cfconv_fused_kernel<WAVES, GAUSS, FAST, NKT, DIAG, COMPACT><<<grid, WAVES * 64, lds, s>>>(args);
   return mp::check_launch("mp_cfconv_fused_f32");
 }
@@ -486,12 +541,35 @@ int cfconv_dispatch(CfconvArgs args, bool gauss, int flags, hipStream_t s) {
     grid = (args.ntiles + 3) / 4 > 256 ? 256 : (args.ntiles + 3) / 4;
     return launch_cfconv<4, true, true, 11, true>(args, grid, s);
   }
+  if (args.bnd_val != nullptr)  // every slot starts empty; the main kernel fills the occupied ones
+    MP_HIP(hipMemsetAsync(args.bnd_node, 0xff, sizeof(int32_t) * 2 * static_cast<size_t>(args.ntiles), s));
+  int rc;
   if (gauss) {
-    return fast ? launch_by_basis<true, true>(args, waves, grid, compact, s)
-                : launch_by_basis<true, false>(args, waves, grid, compact, s);
-  }
-  return fast ? launch_by_basis<false, true>(args, waves, grid, compact, s)
+    rc = fast ? launch_by_basis<true, true>(args, waves, grid, compact, s)
+              : launch_by_basis<true, false>(args, waves, grid, compact, s);
+  } else {
+    rc = fast ? launch_by_basis<false, true>(args, waves, grid, compact, s)
               : launch_by_basis<false, false>(args, waves, grid, compact, s);
+  }
+  if (rc != MP_OK || args.bnd_val == nullptr) return rc;
+  const int64_t nslots = 2 * static_cast<int64_t>(args.ntiles);
+  cfconv_boundary_kernel<<<mp::grid_for(nslots * 32), 256, 0, s>>>(args.bnd_val, args.bnd_node, nslots, args.out);
+  return mp::check_launch("mp_cfconv (deterministic boundary pass)");
+}
+
+inline size_t bnd_val_bytes(int64_t M) { return sizeof(float) * 2 * F * static_cast<size_t>((M + TE - 1) / TE); }
+inline size_t det_ws_bytes(int64_t M) {
+  return ((bnd_val_bytes(M) + 255) & ~static_cast<size_t>(255)) + sizeof(int32_t) * 2 * static_cast<size_t>((M + TE - 1) / TE);
+}
+
+// flags bit 5 (deterministic): carve the boundary buffers out of the caller's workspace
+int attach_det_workspace(CfconvArgs* a, int flags, void* ws, size_t ws_bytes, const char* who) {
+  if (!(flags & 32) || a->M <= 0) return MP_OK;
+  MP_REQUIRE(ws != nullptr && ws_bytes >= det_ws_bytes(a->M), "%s: deterministic mode needs %zu workspace bytes (got %zu)",
+             who, det_ws_bytes(a->M), ws_bytes);
+  a->bnd_val = static_cast<float*>(ws);
+  a->bnd_node = reinterpret_cast<int32_t*>(static_cast<char*>(ws) + ((bnd_val_bytes(a->M) + 255) & ~static_cast<size_t>(255)));
+  return MP_OK;
 }
 
 }  // namespace
@@ -529,6 +607,41 @@ int mp_cfconv_gauss_fused_f32(const float* x, int64_t N, const float* dist, int 
   a.g_distance = distance;
   a.g_gamma = static_cast<float>(1.0 / static_cast<double>(sigma) / static_cast<double>(sigma) / 2.0);
   a.g_offset = offset;
+  return cfconv_dispatch(a, true, flags, mp::as_stream(stream));
+}
+
+int mp_cfconv_det_workspace_bytes(int64_t M, size_t* bytes_out_host) {
+  MP_REQUIRE(M >= 0 && bytes_out_host, "mp_cfconv_det_workspace_bytes: bad arguments");
+  *bytes_out_host = det_ws_bytes(M);
+  return MP_OK;
+}
+
+int mp_cfconv_fused_ws_f32(const float* x, int64_t N, const float* rbf, int B, const float* packed,
+                           const int32_t* recv_sorted, const int32_t* send, const int32_t* perm, int64_t M, int flags,
+                           float* out_zeroed, void* ws, size_t ws_bytes, mpStream_t stream) {
+  CfconvArgs a{};
+  a.x = x; a.edge_in = rbf; a.packed = packed;
+  a.recv = recv_sorted; a.send = send; a.perm = perm; a.out = out_zeroed;
+  a.M = M; a.N = N; a.B = B;
+  const int rc = attach_det_workspace(&a, flags, ws, ws_bytes, "mp_cfconv_fused_ws_f32");
+  if (rc != MP_OK) return rc;
+  return cfconv_dispatch(a, false, flags, mp::as_stream(stream));
+}
+
+int mp_cfconv_gauss_fused_ws_f32(const float* x, int64_t N, const float* dist, int bins, float distance, float sigma,
+                                 float offset, const float* packed, const int32_t* recv_sorted, const int32_t* send,
+                                 const int32_t* perm, int64_t M, int flags, float* out_zeroed, void* ws, size_t ws_bytes,
+                                 mpStream_t stream) {
+  MP_REQUIRE(sigma != 0.0f, "mp_cfconv_gauss_fused_ws_f32: sigma must be non-zero");
+  CfconvArgs a{};
+  a.x = x; a.edge_in = dist; a.packed = packed;
+  a.recv = recv_sorted; a.send = send; a.perm = perm; a.out = out_zeroed;
+  a.M = M; a.N = N; a.B = bins;
+  a.g_distance = distance;
+  a.g_gamma = static_cast<float>(1.0 / static_cast<double>(sigma) / static_cast<double>(sigma) / 2.0);
+  a.g_offset = offset;
+  const int rc = attach_det_workspace(&a, flags, ws, ws_bytes, "mp_cfconv_gauss_fused_ws_f32");
+  if (rc != MP_OK) return rc;
   return cfconv_dispatch(a, true, flags, mp::as_stream(stream));
 }
 

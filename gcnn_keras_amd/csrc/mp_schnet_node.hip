@@ -63,6 +63,28 @@ __device__ __forceinline__ void load_wslice(const float* __restrict__ W, int U, 
     for (int s = 0; s < K / 4; ++s) wr[cb][s] = W[(4 * s + g) * U + col0 + 16 * cb + cc];
 }
 
+// The same slice from a pre-packed image (mp_schnet_node_pack_f32): the lane's registers of four consecutive k-steps are
+// one float4, a wave instruction reads 1 KB contiguous - 16-B loads instead of 4-B loads at a 64-B stride (the weight
+// load is ~a quarter of a node kernel's time at QM9 batch sizes, where every workgroup serves a single tile).
+template <int K, int NCB>
+__device__ __forceinline__ void load_wslice_packed(const float* __restrict__ P, int wave, int lane,
+                                                   float (&wr)[NCB][K / 4]) {
+  const float4* p4 = reinterpret_cast<const float4*>(P);
+#pragma unroll
+  for (int cb = 0; cb < NCB; ++cb)
+#pragma unroll
+    for (int q = 0; q < K / 16; ++q) {
+      const float4 v = p4[((wave * NCB + cb) * (K / 16) + q) * 64 + lane];
+      wr[cb][4 * q + 0] = v.x; wr[cb][4 * q + 1] = v.y; wr[cb][4 * q + 2] = v.z; wr[cb][4 * q + 3] = v.w;
+    }
+}
+template <int K, int NCB, bool PACKED>
+__device__ __forceinline__ void load_w(const float* __restrict__ W, int U, int wave, int lane,
+                                       float (&wr)[NCB][K / 4]) {
+  if constexpr (PACKED) load_wslice_packed<K, NCB>(W, wave, lane, wr);
+  else load_wslice<K, NCB>(W, U, wave * (U / 4), lane, wr);
+}
+
 // acc[rb][cb] += Xs(16*RB x K) @ Wslice ; A operand from LDS: lane supplies Xs[node = 16 rb + (lane&15)][k = 4s + (lane>>4)];
 // every weight register feeds RB MFMAs.
 template <int K, int NCB, int RB>
@@ -85,6 +107,8 @@ __device__ __forceinline__ void gemm_tile(const float* __restrict__ Xs, int lane
 struct NodeArgs {
   int64_t N;
   int ntiles;
+  int keep_agg;          // do not re-zero the consumed aggregation rows (layer API: the rows belong to the caller)
+  float* n_out;          // UPD: updated node state (n itself is read only)
   // IN
   const float* numbers;  // (N) float node numbers
   const float* emb;      // (vocab, E)
@@ -109,7 +133,8 @@ struct NodeArgs {
   float* h;              // (N, 64)
 };
 
-enum NodeMode { NODE_IN = 0, NODE_MID = 1, NODE_LAST = 2 };
+// UPD = MID without the next block's Dense_nobias, out of place: SchNetInteraction.call's node side on its own
+enum NodeMode { NODE_IN = 0, NODE_MID = 1, NODE_LAST = 2, NODE_UPD = 3 };
 
 // Epilogue helper: visit the wave's output elements.  C layout of 16x16x4: col = lane&15, row = 4*(lane>>4) + r.
 #define MP_FOR_OUT(cb, r, row, col, body)                             \
@@ -125,7 +150,7 @@ enum NodeMode { NODE_IN = 0, NODE_MID = 1, NODE_LAST = 2 };
 
 // `block` / `nblocks`: this workgroup's position among the workgroups running the node chain (the stage-0 kernel runs
 // edge preparation on the remaining workgroups of the same launch).
-template <int MODE, int E, int RB, bool FAST>
+template <int MODE, int E, int RB, bool FAST, bool PACKED>
 __device__ __forceinline__ void schnet_node_body(const NodeArgs& a, int block, int nblocks) {
   __shared__ float Xa[16 * RB * X_LD];
   __shared__ float Xb[16 * RB * X_LD];
@@ -170,7 +195,7 @@ __device__ __forceinline__ void schnet_node_body(const NodeArgs& a, int block, i
         if (t < a.ntiles && node < a.N) {
           float4* p = reinterpret_cast<float4*>(a.agg + node * F) + k4;
           v = *p;
-          *p = make_float4(0.f, 0.f, 0.f, 0.f);
+          if (!a.keep_agg) *p = make_float4(0.f, 0.f, 0.f, 0.f);
         }
         stg[j] = v;
       }
@@ -197,19 +222,19 @@ __device__ __forceinline__ void schnet_node_body(const NodeArgs& a, int block, i
   // ---- weight slices -> registers (once per persistent workgroup) -------------------------------------------
   float w_first[2][(MODE == NODE_IN ? E : F) / 4];   // IN: W0 ; MID/LAST: W2
   float w_second[2][F / 4];                          // IN: Wx ; MID/LAST: W3
-  float w_third[2][(MODE == NODE_IN ? 4 : F) / 4];   // MID: Wx ; LAST: Wl0
+  float w_third[2][((MODE == NODE_IN || MODE == NODE_UPD) ? 4 : F) / 4];   // MID: Wx ; LAST: Wl0
   float w_fourth[1][(MODE == NODE_LAST ? F : 4) / 4];  // LAST: Wl1 (16 columns per wave)
   float bias_first[2], bias_second[2], bias_third[2], bias_fourth;
   if constexpr (MODE == NODE_IN) {
-    load_wslice<E, 2>(a.W0, F, wave * 32, lane, w_first);
-    load_wslice<F, 2>(a.Wx, F, wave * 32, lane, w_second);
+    load_w<E, 2, PACKED>(a.W0, F, wave, lane, w_first);
+    load_w<F, 2, PACKED>(a.Wx, F, wave, lane, w_second);
   } else {
-    load_wslice<F, 2>(a.W2, F, wave * 32, lane, w_first);
-    load_wslice<F, 2>(a.W3, F, wave * 32, lane, w_second);
-    if constexpr (MODE == NODE_MID) load_wslice<F, 2>(a.Wx, F, wave * 32, lane, w_third);
+    load_w<F, 2, PACKED>(a.W2, F, wave, lane, w_first);
+    load_w<F, 2, PACKED>(a.W3, F, wave, lane, w_second);
+    if constexpr (MODE == NODE_MID) load_w<F, 2, PACKED>(a.Wx, F, wave, lane, w_third);
     if constexpr (MODE == NODE_LAST) {
-      load_wslice<F, 2>(a.Wl0, F, wave * 32, lane, w_third);
-      load_wslice<F, 1>(a.Wl1, 64, wave * 16, lane, w_fourth);
+      load_w<F, 2, PACKED>(a.Wl0, F, wave, lane, w_third);
+      load_w<F, 1, PACKED>(a.Wl1, 64, wave, lane, w_fourth);
     }
   }
 #pragma unroll
@@ -291,8 +316,10 @@ __device__ __forceinline__ void schnet_node_body(const NodeArgs& a, int block, i
         const float y = acc[rb][cb][r] + bias_second[cb];
         const float nn = n_res[rb][cb][r] + y;  // LazyAdd([node, x])
         if (ok && MODE == NODE_MID) a.n[(node0 + row) * F + col] = nn;
-        Xa[row * X_LD + col] = nn;
+        if (ok && MODE == NODE_UPD) a.n_out[(node0 + row) * F + col] = nn;
+        if constexpr (MODE != NODE_UPD) Xa[row * X_LD + col] = nn;
       })
+      if constexpr (MODE != NODE_UPD) {
       __syncthreads();
       MP_NSTAMP(4)
 
@@ -322,6 +349,7 @@ __device__ __forceinline__ void schnet_node_body(const NodeArgs& a, int block, i
             if (node0 + row < a.N) a.h[(node0 + row) * 64 + col] = ssp<FAST>(acc4[rb][0][r] + bias_fourth);
           }
       }
+      }
     }
     __syncthreads();  // Xa / Xb are reused by the next tile
     MP_NSTAMP(6)
@@ -333,18 +361,18 @@ __device__ __forceinline__ void schnet_node_body(const NodeArgs& a, int block, i
 #endif
 }
 
-template <int MODE, int E, int RB, bool FAST>
+template <int MODE, int E, int RB, bool FAST, bool PACKED>
 __global__ __launch_bounds__(256, MODE != NODE_LAST ? 2 : 1) void schnet_node_kernel(NodeArgs a) {
-  schnet_node_body<MODE, E, RB, FAST>(a, blockIdx.x, gridDim.x);
+  schnet_node_body<MODE, E, RB, FAST, PACKED>(a, blockIdx.x, gridDim.x);
 }
 
 // Stage 0 of the fused forward: the node-input chain (Embedding -> Dense -> Dense_nobias) and the edge preparation
 // (index shift, receiver/sender split, flags, distance) are independent, and at QM9 batch sizes each alone fills less
 // than half of the chip for ~5 us - so one launch runs both, on disjoint workgroups (role by block index).
-template <int E, bool FAST, bool LDS_SPLITS>
+template <int E, bool FAST, bool LDS_SPLITS, bool PACKED>
 __global__ __launch_bounds__(256) void schnet_stage0_kernel(NodeArgs a, mp_prep::EdgePrepArgs p, int node_blocks) {
   if (static_cast<int>(blockIdx.x) < node_blocks) {
-    schnet_node_body<NODE_IN, E, 1, FAST>(a, blockIdx.x, node_blocks);
+    schnet_node_body<NODE_IN, E, 1, FAST, PACKED>(a, blockIdx.x, node_blocks);
   } else {
     mp_prep::edge_prepare_body<LDS_SPLITS>(p, static_cast<int64_t>(blockIdx.x) - node_blocks,
                                            static_cast<int64_t>(gridDim.x) - node_blocks);
@@ -399,17 +427,39 @@ __global__ __launch_bounds__(256) void schnet_readout_kernel(const float* __rest
 // serialisation was gone - 64-node tiles spill the weights, 32-node tiles spill ~25 registers whose reloads queue behind
 // the tile prefetch (3371 vs 3328 us per forward at 225 k nodes, 397 vs 380 us at 18 k).  The persistent grid is two
 // workgroups per CU.
-template <int MODE, int E, bool FAST>
+template <int MODE, int E, bool FAST, bool PACKED>
 int launch_node_impl(NodeArgs a, hipStream_t s, const char* what) {
   a.ntiles = static_cast<int>((a.N + 15) / 16);
   const int grid = a.ntiles < 512 ? a.ntiles : 512;
-  schnet_node_kernel<MODE, E, 1, FAST><<<grid, 256, 0, s>>>(a);
+  schnet_node_kernel<MODE, E, 1, FAST, PACKED><<<grid, 256, 0, s>>>(a);
   return mp::check_launch(what);
+}
+
+// Pre-packed image of a Keras kernel W (K, U), U = 64 * NCB: element i = (((w * NCB + cb) * (K/16) + q) * 64 + lane) * 4 + j
+// holds W[k = 4 * (4q + j) + (lane >> 4)][col = w * (U/4) + 16 cb + (lane & 15)] - the order load_wslice_packed reads.
+__global__ void node_pack_kernel(const float* __restrict__ W, int K, int U, float* __restrict__ packed) {
+  const int ncb = U / 64, total = K * U;
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
+    const int j = i & 3, lane = (i >> 2) & 63;
+    int rest = i >> 8;
+    const int q = rest % (K / 16);
+    rest /= (K / 16);
+    const int cb = rest % ncb, w = rest / ncb;
+    const int k = 4 * (4 * q + j) + (lane >> 4);
+    const int col = w * (U / 4) + 16 * cb + (lane & 15);
+    packed[i] = W[k * U + col];
+  }
 }
 
 template <int MODE, int E>
 int launch_node(const NodeArgs& a, int flags, hipStream_t s, const char* what) {
-  return (flags & 1) ? launch_node_impl<MODE, E, true>(a, s, what) : launch_node_impl<MODE, E, false>(a, s, what);
+  if constexpr (MODE != NODE_UPD) {   // flags bit 1: the weight pointers are mp_schnet_node_pack_f32 images
+    if (flags & 2)
+      return (flags & 1) ? launch_node_impl<MODE, E, true, true>(a, s, what)
+                         : launch_node_impl<MODE, E, false, true>(a, s, what);
+  }
+  return (flags & 1) ? launch_node_impl<MODE, E, true, false>(a, s, what)
+                     : launch_node_impl<MODE, E, false, false>(a, s, what);
 }
 
 }  // namespace
@@ -461,10 +511,12 @@ int mp_schnet_stage0_f32(const float* numbers, int64_t N, const float* emb, int 
   const int node_blocks = a.ntiles;
   const int edge_blocks = static_cast<int>(mp::grid_for(M));
   hipStream_t s = mp::as_stream(stream);
-  if (flags_arg & 1) {
-    schnet_stage0_kernel<64, true, true><<<node_blocks + edge_blocks, 256, 0, s>>>(a, p, node_blocks);
-  } else {
-    schnet_stage0_kernel<64, false, true><<<node_blocks + edge_blocks, 256, 0, s>>>(a, p, node_blocks);
+  const unsigned grid = static_cast<unsigned>(node_blocks + edge_blocks);
+  switch (flags_arg & 3) {
+    case 0: schnet_stage0_kernel<64, false, true, false><<<grid, 256, 0, s>>>(a, p, node_blocks); break;
+    case 1: schnet_stage0_kernel<64, true, true, false><<<grid, 256, 0, s>>>(a, p, node_blocks); break;
+    case 2: schnet_stage0_kernel<64, false, true, true><<<grid, 256, 0, s>>>(a, p, node_blocks); break;
+    default: schnet_stage0_kernel<64, true, true, true><<<grid, 256, 0, s>>>(a, p, node_blocks); break;
   }
   return mp::check_launch("mp_schnet_stage0_f32");
 }
@@ -479,6 +531,26 @@ int mp_schnet_node_update_f32(float* agg, int64_t N, const float* W2, const floa
   a.N = N;
   a.agg = agg; a.W2 = W2; a.b2 = b2; a.W3 = W3; a.b3 = b3; a.n = n_inout; a.Wx = Wx_next; a.x = x_out;
   return launch_node<NODE_MID, 64>(a, flags, mp::as_stream(stream), "mp_schnet_node_update_f32");
+}
+
+int mp_schnet_node_pack_f32(const float* W, int K, int U, float* packed, mpStream_t stream) {
+  MP_REQUIRE(W && packed, "mp_schnet_node_pack_f32: null pointer");
+  MP_REQUIRE(K >= 16 && K % 16 == 0 && U >= 64 && U % 64 == 0, "mp_schnet_node_pack_f32: K %% 16 == 0 and U %% 64 == 0 "
+             "required (got %d x %d)", K, U);
+  node_pack_kernel<<<64, 256, 0, mp::as_stream(stream)>>>(W, K, U, packed);
+  return mp::check_launch("mp_schnet_node_pack_f32");
+}
+
+int mp_schnet_node_residual_f32(const float* agg, int64_t N, const float* W2, const float* b2, const float* W3,
+                                const float* b3, const float* n_in, float* n_out, int flags, mpStream_t stream) {
+  MP_REQUIRE(N >= 0, "mp_schnet_node_residual_f32: bad sizes");
+  if (N == 0) return MP_OK;
+  MP_REQUIRE(agg && W2 && W3 && n_in && n_out, "mp_schnet_node_residual_f32: null pointer");
+  NodeArgs a{};
+  a.N = N;
+  a.agg = const_cast<float*>(agg); a.keep_agg = 1;
+  a.W2 = W2; a.b2 = b2; a.W3 = W3; a.b3 = b3; a.n = const_cast<float*>(n_in); a.n_out = n_out;
+  return launch_node<NODE_UPD, 64>(a, flags, mp::as_stream(stream), "mp_schnet_node_residual_f32");
 }
 
 int mp_schnet_node_last_f32(float* agg, int64_t N, const float* W2, const float* b2, const float* W3, const float* b3,

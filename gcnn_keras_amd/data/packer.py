@@ -140,12 +140,43 @@ def pack_edge_index(index_arrays, node_counts, buffers=None, threads=4, with_csr
 
 class PackedBatch(dict):
     """Name -> device tensor (``RaggedTensor`` for ragged items, ``torch.Tensor`` otherwise) plus ``.ready``, a
-    ``torch.cuda.Event`` recorded on the copy stream after the last copy of the batch."""
+    ``torch.cuda.Event`` recorded on the copy stream after the last copy of the batch.
+
+    Every device tensor of the batch is allocated on the packer's copy stream, so the caching allocator would hand its
+    memory to the NEXT ``pack()`` as soon as the batch is dropped - while kernels of the consumer stream may still be
+    queued on it.  ``wait(stream)`` therefore does both halves of the hand-over: the consumer stream waits for the copies,
+    and every tensor (values, row_splits, the plan's columns / CSR / flag word) is registered with the consumer stream
+    (``Tensor.record_stream``), which keeps its block out of the copy stream's pool until that stream has passed the
+    point of release."""
     ready = None
 
+    def device_tensors(self):
+        seen = set()
+
+        def emit(t):
+            if torch.is_tensor(t) and t.is_cuda and id(t) not in seen:
+                seen.add(id(t))
+                yield t
+
+        for value in self.values():
+            if isinstance(value, RaggedTensor):
+                yield from emit(value.values)
+                yield from emit(value.row_splits)
+                for plan in value._plans.values():
+                    yield from emit(plan.cols)
+                    yield from emit(plan.flags)
+                    for entry in plan._csr.values():
+                        for t in entry:
+                            yield from emit(t)
+            else:
+                yield from emit(value)
+
     def wait(self, stream=None):
+        stream = stream or torch.cuda.current_stream()
         if self.ready is not None:
-            (stream or torch.cuda.current_stream()).wait_event(self.ready)
+            stream.wait_event(self.ready)
+        for t in self.device_tensors():
+            t.record_stream(stream)
         return self
 
 

@@ -1,9 +1,10 @@
 """Whole-forward drivers of the SchNet hot path (kgcnn/literature/Schnet.py:104-148) on one GPU.
 
-``SchnetForward`` owns a resident batch and runs one forward per ``forward()`` call in one of two modes:
+``SchnetForward`` owns resident batches and calls ``Schnet.make_model(...)(inputs)`` on them, in one of two modes:
 
-* ``layers``: the reference's layer graph, one engine primitive per Keras layer (gcnn_keras_amd.layers.*).
-* ``fused``:  the same arithmetic in a handful of fused kernels replayed from a HIP graph (csrc/mp_schnet_*.hip).
+* ``layers``: the reference's layer graph, one engine primitive per Keras layer (``model(inputs, fused=False)``).
+* ``fused``:  the model's own fused route - the same arithmetic in eight kernels replayed from a HIP graph
+  (csrc/mp_schnet_*.hip, gcnn_keras_amd/fused.py).
 
 Both go through the C ABI only; there is no CPU path.
 """
@@ -43,11 +44,15 @@ class _HipTimer:
 
 
 class SchnetForward:
-    """``in_flight`` (fused mode): number of independent batch slots, each with its own buffers, HIP stream and captured
-    graph.  A 128-graph batch fills neither the chip (819 edge tiles on 1024 SIMDs, 144 node tiles on 256 CUs) nor a
-    SIMD's matrix pipe (FP32 MFMA and the wave's own vector phases exclude each other), so a serving / training loop
-    that keeps several batches in flight lets the kernels of different batches share CUs: ``forward(i)`` runs slot
-    ``i % in_flight`` on that slot's stream."""
+    """Bench / test harness around ``Schnet.make_model``: owns resident batches and calls the model on them.
+
+    ``mode="fused"`` lets the model take its fused route (``model.fused``, gcnn_keras_amd/fused.py), ``"layers"`` forces
+    the reference's layer sequence (``model(inputs, fused=False)``).  ``in_flight``: number of independent input sets
+    (each bound to its own batch slot by the model) served round-robin on their own HIP streams - a 128-graph batch
+    fills neither the chip (819 edge tiles on 1024 SIMDs, 144 node tiles on 256 CUs) nor a SIMD's matrix pipe (FP32 MFMA
+    and the wave's own vector phases exclude each other), so a serving loop that keeps several batches in flight lets
+    the kernels of different batches share CUs: ``replay(i)`` is ``model(inputs[i % in_flight])`` on stream
+    ``i % in_flight``."""
 
     def __init__(self, params, depth=3, mode="auto", units=128, bins=20, gauss_args=None, in_flight=1):
         from .literature import Schnet
@@ -57,23 +62,28 @@ class SchnetForward:
         self.depth = depth
         self.units = units
         self.gauss_args = gauss_args or {"bins": bins, "distance": 4, "offset": 0.0, "sigma": 0.4}
-        if mode == "auto":
-            mode = "fused" if _fused_available() else "layers"
-        self.mode = mode
-        self.num_launches = None
         self.model = Schnet.make_model(depth=depth, gauss_args=self.gauss_args)
         self.model.set_weights(list(params.values()))
+        if mode == "auto":
+            mode = "fused" if self.model.fused is not None else "layers"
+        if mode == "fused" and self.model.fused is None:
+            raise ValueError("this SchNet configuration does not fit the fused kernels")
+        self.mode = mode
+        self.num_launches = None
         self._batch = None
-        self._fused = None
+        self._inputs = []
+        self._streams = []
         self._slots = []
         self.in_flight = max(1, int(in_flight)) if mode == "fused" else 1
-        if mode == "fused":
-            from .fused import FusedSchnet
+        if mode == "fused" and self.in_flight > 1:
             # several forwards in flight: the 256-register / 79 KB cfconv build lets two workgroups share a CU
-            flags = 16 if self.in_flight > 1 else 0
-            self._slots = [FusedSchnet(params, depth=depth, gauss_args=self.gauss_args, cfconv_flags=flags)
-                           for _ in range(self.in_flight)]
-            self._fused = self._slots[0]
+            self.model.fused.cfconv_flags = 16
+        if mode == "fused":
+            self.model.fused.max_slots = max(self.model.fused.max_slots, self.in_flight)
+
+    @property
+    def _fused(self):
+        return self._slots[0] if self._slots else None
 
     # ------------------------------------------------------------------------------------------------ batch
     def load_batch(self, batch):
@@ -90,22 +100,31 @@ class SchnetForward:
         self.N = int(batch["node_splits"][-1])
         self.M = int(batch["edge_splits"][-1])
         self.G = len(batch["node_splits"]) - 1
-        for k, slot in enumerate(self._slots):
+        if self.mode != "fused":
+            return
+        self.model.fused.release()
+        self._inputs, self._streams, self._slots = [], [], []
+        for k in range(self.in_flight):
             # every slot owns a copy of the inputs, as it would hold a different batch in production
             own = self._batch if k == 0 else {key: (v.clone() if torch.is_tensor(v) else v)
                                               for key, v in self._batch.items()}
-            slot.bind(own, self.N, self.M, self.G)
-            slot.forward()  # captures the slot's graph now, outside any timed region
+            self._inputs.append(self._ragged_inputs(own))
+            self._streams.append(torch.cuda.Stream())
+        torch.cuda.synchronize()
+        for k in range(self.in_flight):
+            with torch.cuda.stream(self._streams[k]):
+                self.model(self._inputs[k])   # binds the batch slot (index pass, buffers), direct launch
+                self.model(self._inputs[k])   # captures the slot's graph now, outside any timed region
+            self._slots.append(self.model.fused.slot_of(self._inputs[k]))
         torch.cuda.synchronize()
         if self.in_flight > 1:
             self._place_streams()
 
     def _place_streams(self, draws=4, steps=120):
-        """How well forwards in flight overlap depends on which hardware queues the slots' streams land on (the ROCm
-        runtime multiplexes streams onto a few queues; a slot sharing a queue with another stream serialises behind it:
-        measured 48 vs 64 us per step for different draws of four streams from torch's pool).  A captured graph can be
-        launched on any stream, so this draws the slots' streams a few times, measures ~100 replays each and keeps the
-        best draw.  Runs once per ``load_batch``, outside any timed region (~30 ms)."""
+        """How well forwards in flight overlap depends on which hardware queues the streams land on (the ROCm runtime
+        multiplexes streams onto a few queues; a stream sharing a queue with another serialises behind it: measured 48 vs
+        64 us per step for different draws of four streams from torch's pool).  This draws the streams a few times,
+        measures ~100 forwards each and keeps the best draw.  Runs once per ``load_batch``, outside any timed region."""
         import time
 
         def rate():
@@ -122,19 +141,13 @@ class SchnetForward:
         for _ in range(draws):
             t = rate()
             if best is None or t < best:
-                best, best_streams = t, [slot.stream for slot in self._slots]
-            for slot in self._slots:
-                slot.stream = torch.cuda.Stream()
-                slot._stream_ptr = None
-        for slot, st in zip(self._slots, best_streams):
-            slot.stream = st
-            slot._stream_ptr = None
+                best, best_streams = t, list(self._streams)
+            self._streams = [torch.cuda.Stream() for _ in range(self.in_flight)]
+        self._streams = best_streams
         torch.cuda.synchronize()
 
-    def _fresh_inputs(self):
-        """New ragged wrappers every step, so nothing cached on them (index plan, CSR) leaks across steps."""
-        b = self._batch
-
+    @staticmethod
+    def _ragged_inputs(b):
         def rag(v, s, sh):
             r = RaggedTensor(v, s)
             r._splits_host = sh  # partition sizes are batch metadata from the host-side loader
@@ -143,39 +156,46 @@ class SchnetForward:
         return [rag(b["z"], b["ns"], b["ns_host"]), rag(b["xyz"], b["ns"], b["ns_host"]),
                 rag(b["idx"], b["es"], b["es_host"])]
 
+    def _fresh_inputs(self):
+        """New ragged wrappers every step, so nothing cached on them (index plan, CSR) leaks across steps."""
+        return self._ragged_inputs(self._batch)
+
     # ------------------------------------------------------------------------------------------------ forward
     def forward(self, step=0):
-        if self._fused is not None:
-            return self._slots[step % self.in_flight].forward()
+        """``model(inputs)`` on the caller's current stream (slot ``step % in_flight``'s inputs)."""
+        if self.mode == "fused":
+            return self.model(self._inputs[step % self.in_flight])
         before = _ffi.launch_count()
-        out = self.model(self._fresh_inputs())
+        out = self.model(self._fresh_inputs(), fused=False)
         self.num_launches = _ffi.launch_count() - before
         return out
 
     def replay(self, step=0):
-        """Fused mode: launch slot ``step % in_flight``'s captured forward on its own stream (one C-ABI call, no stream
-        context switching on the host); layers mode: same as ``forward``."""
-        if self._fused is not None:
-            return self._slots[step % self.in_flight].replay()
+        """Fused mode: ``model(inputs[k])`` on stream ``k = step % in_flight`` (a re-bound batch: the model replays the
+        slot's captured graph - one hipGraphLaunch - and copies the (G,1) result out); layers mode: same as ``forward``."""
+        if self.mode == "fused":
+            k = step % self.in_flight
+            with torch.cuda.stream(self._streams[k]):
+                return self.model(self._inputs[k])
         return self.forward(step)
 
     @property
     def stream(self):
-        """The HIP stream the forward is replayed on (run the step loop under ``torch.cuda.stream(fwd.stream)``)."""
-        return self._fused.stream if self._fused is not None else torch.cuda.current_stream()
+        """The HIP stream slot 0 is served on."""
+        return self._streams[0] if self._streams else torch.cuda.current_stream()
 
     def stream_of(self, step):
         """Stream of the slot that serves ``step``."""
-        return self._slots[step % self.in_flight].stream if self._slots else torch.cuda.current_stream()
+        return self._streams[step % self.in_flight] if self._streams else torch.cuda.current_stream()
 
     def check_flags(self):
-        for slot in self._slots:
-            slot.check_flags()
+        if self.model.fused is not None:
+            self.model.fused.check_flags()
 
     # ------------------------------------------------------------------------------------------------ roofline
     def roofline(self, hbm_peak_gbs, mfma_peak_tf, iters=50):
         """Dominant kernel of the forward, timed live with HIP events on the stream it is launched on."""
-        if self._fused is not None:
+        if self.mode == "fused":
             self.num_launches = self._fused.num_launches
             return self._fused.roofline(hbm_peak_gbs, mfma_peak_tf, iters)
         # layers mode: the per-edge filter GEMM (M,128)x(128,128) of SchNetCFconv.lay_dense2 dominates
@@ -257,11 +277,3 @@ class GraphedModelPool:
         ev = self._events[step % self.in_flight]
         if ev is not None:
             torch.cuda.current_stream().wait_event(ev)
-
-
-def _fused_available():
-    try:
-        lib = _ffi.lib()
-        return hasattr(lib, "mp_cfconv_gauss_fused_f32")
-    except Exception:
-        return False

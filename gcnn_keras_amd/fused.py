@@ -16,52 +16,105 @@ import torch
 from . import _ffi
 
 
+_SSP = ("kgcnn>shifted_softplus", "shifted_softplus")
+_SUM = ("sum", "segment_sum", "reduce_sum")
+
+
+def _as_list(v, n):
+    return list(v) if isinstance(v, (list, tuple)) else [v] * n
+
+
 def supports(config):
-    """True if a Schnet.make_model configuration maps onto the fused kernels (else use the layer path)."""
-    ia = config["interaction_args"]
-    return (ia.get("units") == 128 and ia.get("cfconv_pool") in ("sum", "segment_sum", "reduce_sum")
-            and ia.get("activation") in ("kgcnn>shifted_softplus", "shifted_softplus") and ia.get("use_bias", True)
+    """True if a ``Schnet.make_model`` configuration (the merged keyword dictionary) maps onto the fused kernels:
+    float node numbers through a 64-wide embedding, distances and Gauss basis made inside the model, 128 units with
+    shifted softplus and sum pooling, ``last_mlp`` [128, 64] / ``output_mlp`` [64, 1], graph output.  Anything else
+    runs the layer path (kgcnn/literature/Schnet.py:104-148 op by op)."""
+    try:
+        ia, lm, om = config["interaction_args"], config["last_mlp"], config["output_mlp"]
+        inputs = config.get("inputs")
+        if inputs is not None and (len(inputs[0]["shape"]) != 1 or tuple(inputs[1]["shape"])[-1] != 3):
+            return False
+        return bool(
+            config.get("make_distance", True) and config.get("expand_distance", True)
+            and config.get("use_output_mlp", True) and config.get("output_embedding", "graph") == "graph"
+            and ia.get("units") == 128 and ia.get("cfconv_pool", "sum") in _SUM
+            and ia.get("activation", _SSP[0]) in _SSP and ia.get("use_bias", True) is True
             and config["input_embedding"]["node"]["output_dim"] == 64
-            and list(config["last_mlp"]["units"]) == [128, 64]
-            and list(config["output_mlp"]["units"]) == [64, 1]
-            and config["node_pooling_args"].get("pooling_method") in ("sum", "segment_sum", "reduce_sum")
-            and config.get("output_embedding", "graph") == "graph"
-            and int(config["gauss_args"]["bins"]) <= 32)
+            and _as_list(lm["units"], 1) == [128, 64] and _as_list(lm.get("activation"), 2) in ([_SSP[0]] * 2, [_SSP[1]] * 2)
+            and all(_as_list(lm.get("use_bias", True), 2))
+            and _as_list(om["units"], 1) == [64, 1] and _as_list(om.get("activation"), 2)[0] in _SSP
+            and _as_list(om.get("activation"), 2)[1] in ("linear", None) and all(_as_list(om.get("use_bias", True), 2))
+            and config["node_pooling_args"].get("pooling_method") in _SUM
+            and 1 <= int(config["gauss_args"]["bins"]) <= 32 and float(config["gauss_args"]["sigma"]) != 0.0
+            and int(config["depth"]) >= 1)
+    except (KeyError, TypeError, IndexError):
+        return False
+
+
+def node_weight_names(depth):
+    """Keras kernels the node-side kernels read as ``mp_schnet_node_pack_f32`` images."""
+    names = ["dense0/kernel", "last_mlp/0/kernel", "last_mlp/1/kernel"]
+    for i in range(depth):
+        names += ["interaction%d/dense%d/kernel" % (i, k) for k in (1, 2, 3)]
+    return names
+
+
+def pack_weights(p, depth, bins, out=None):
+    """Kernel-side images of the weights: ``mp_cfconv_pack_f32`` (filter MLP of every interaction block in the cfconv
+    kernel's LDS order) and ``mp_schnet_node_pack_f32`` (node-side matrices in register-slice order).  Packed once per
+    weight update; ``out`` re-fills existing images in place (captured graphs keep pointing at them)."""
+    nfl = _ffi.lib().mp_cfconv_packed_floats()
+    if out is None:
+        out = {"cfconv": [torch.empty(nfl, dtype=torch.float32, device="cuda") for _ in range(depth)],
+               "node": {k: torch.empty(p[k].numel(), dtype=torch.float32, device="cuda")
+                        for k in node_weight_names(depth)}}
+    for i in range(depth):
+        pre = "interaction%d/cfconv/" % i
+        _ffi.call("mp_cfconv_pack_f32", _ffi.ptr(p[pre + "dense1/kernel"]), _ffi.ptr(p.get(pre + "dense1/bias")),
+                  int(bins), _ffi.ptr(p[pre + "dense2/kernel"]), _ffi.ptr(p.get(pre + "dense2/bias")),
+                  _ffi.ptr(out["cfconv"][i]), _ffi.stream())
+    for k, image in out["node"].items():
+        _ffi.call("mp_schnet_node_pack_f32", _ffi.ptr(p[k]), int(p[k].shape[0]), int(p[k].shape[1]), _ffi.ptr(image),
+                  _ffi.stream())
+    torch.cuda.current_stream().synchronize()
+    return out
 
 
 class FusedSchnet:
-    def __init__(self, params, depth=3, gauss_args=None, fast_softplus=True, use_graph=True, cfconv_flags=0):
+    """One batch slot of the fused forward: work buffers, a HIP stream and the captured graph of ONE bound batch.
+
+    ``params`` maps the names of ``gcnn_keras_amd.synth.schnet_params`` to NumPy arrays (copied to HBM) or to device
+    tensors (used in place: the slots of a ``Schnet.make_model`` model read the model's own weight tensors).
+    ``packed`` optionally shares the weight images (``pack_weights``) of another slot of the same model."""
+
+    def __init__(self, params, depth=3, gauss_args=None, fast_softplus=True, use_graph=True, cfconv_flags=0,
+                 packed=None):
         if not torch.cuda.is_available():
             raise _ffi.EngineError("FusedSchnet needs an MI355X (no CPU fallback)")
         self.depth = depth
         self.gauss = dict(gauss_args or {"bins": 20, "distance": 4, "offset": 0.0, "sigma": 0.4})
-        self.flags_arg = (1 if fast_softplus else 0) | int(cfconv_flags)
+        self.flags_arg = (1 if fast_softplus else 0) | 2 | int(cfconv_flags)   # bit 1: node weights as packed images
         self._stream_ptr = None
-        self._desc = None
+        self._desc = self._desc_ref = None
         self.use_graph = use_graph
-        self.p = {k: torch.from_numpy(np.ascontiguousarray(v, dtype=np.float32)).cuda() for k, v in params.items()}
+        self.p = {k: (v if torch.is_tensor(v) else torch.from_numpy(np.ascontiguousarray(v, dtype=np.float32)).cuda())
+                  for k, v in params.items() if v is not None}
         if tuple(self.p["embedding"].shape)[1] != 64 or tuple(self.p["dense0/kernel"].shape) != (64, 128):
             raise ValueError("FusedSchnet is built for embedding width 64 and 128 units")
         # filter-MLP weights of every block in the cfconv kernel's LDS image order (packed once per weight update)
-        nfl = _ffi.lib().mp_cfconv_packed_floats()
-        self.packed = []
-        for i in range(depth):
-            pre = "interaction%d/cfconv/" % i
-            buf = torch.empty(nfl, dtype=torch.float32, device="cuda")
-            _ffi.call("mp_cfconv_pack_f32", _ffi.ptr(self.p[pre + "dense1/kernel"]),
-                      _ffi.ptr(self.p.get(pre + "dense1/bias")), int(self.gauss["bins"]),
-                      _ffi.ptr(self.p[pre + "dense2/kernel"]), _ffi.ptr(self.p.get(pre + "dense2/bias")),
-                      _ffi.ptr(buf), _ffi.stream())
-            self.packed.append(buf)
-        torch.cuda.synchronize()
+        images = packed if packed is not None else pack_weights(self.p, depth, int(self.gauss["bins"]))
+        self.packed, self.node_images = images["cfconv"], images["node"]
         self.stream = torch.cuda.Stream()
         self.graph = None
         self.num_launches = 1 + 2 * depth + 1
         self._b = None
 
     # ------------------------------------------------------------------------------------------------ binding
-    def bind(self, b, n, m, g):
-        """Attach a resident batch (dict of device tensors: z, xyz, idx, ns, es) and allocate all work buffers."""
+    def bind(self, b, n, m, g, known_flags=None):
+        """Attach a resident batch (dict of device tensors: z, xyz, idx, ns, es + host node splits) and allocate all
+        work buffers on the current stream.  ``known_flags``: the MP_FLAG_* word of the index list if a producer (host
+        packer, on-GPU SetRange) already established it - otherwise one index pass runs and its flag word is read back
+        (the only host synchronisation of a batch's life, on the current stream only)."""
         self._b, self.N, self.M, self.G = b, n, m, g
         dev = "cuda"
         self.recv = torch.empty(max(m, 1), dtype=torch.int32, device=dev)
@@ -75,9 +128,12 @@ class FusedSchnet:
         self.out = torch.zeros((g, 1), dtype=torch.float32, device=dev)
         self.perm = self.recv_sorted = self.sort_ws = None
         # sortedness of the receiver column is a property of the batch: decide once, outside the timed region
-        self._prepare()
-        torch.cuda.synchronize()
-        f = int(self.flags.item())
+        if known_flags is None:
+            self._prepare()
+            f = int(self.flags.item())
+            self.flags.zero_()
+        else:
+            f = int(known_flags)
         if f & _ffi.MP_FLAG_OOB:
             raise IndexError("edge index out of range for its graph")
         self.sorted = not (f & _ffi.MP_FLAG_UNSORTED_COL0)
@@ -88,15 +144,13 @@ class FusedSchnet:
             self.sort_ws_bytes = nbytes.value
             self.recv_sorted = torch.empty(m, dtype=torch.int32, device=dev)
             self.perm = torch.empty(m, dtype=torch.int32, device=dev)
-        self.flags.zero_()
         splits = np.asarray(b["ns_host"])
         rows = g
         while rows > 0 and splits[rows] == splits[rows - 1]:
             rows -= 1
         self.out_rows = rows  # tf.math.segment_sum drops trailing empty graphs (kgcnn/layers/pooling.py:215-219)
         self.graph = None
-        self._desc = None
-        torch.cuda.synchronize()
+        self._desc = self._desc_ref = None
 
     def _prepare(self):
         b = self._b
@@ -115,42 +169,74 @@ class FusedSchnet:
     def _launch_all(self):
         # One linear chain on one stream.  (A two-branch graph - node_in beside edge_prepare - was measured 9 % SLOWER
         # at config 2: the fork/join costs more than the ~5 us of overlap it buys.)
-        p, b = self.p, self._b
+        p, b, w = self.p, self._b, self.node_images
         if self.sorted or self.M == 0:
             # stage 0: node-input chain and edge preparation in one launch (independent work on disjoint workgroups)
             _ffi.call("mp_schnet_stage0_f32", _ffi.ptr(b["z"]), self.N, _ffi.ptr(p["embedding"]),
-                      int(p["embedding"].shape[0]), 64, _ffi.ptr(p["dense0/kernel"]), _ffi.ptr(p.get("dense0/bias")),
-                      _ffi.ptr(p["interaction0/dense1/kernel"]), _ffi.ptr(self.n), _ffi.ptr(self.x),
+                      int(p["embedding"].shape[0]), 64, _ffi.ptr(w["dense0/kernel"]), _ffi.ptr(p.get("dense0/bias")),
+                      _ffi.ptr(w["interaction0/dense1/kernel"]), _ffi.ptr(self.n), _ffi.ptr(self.x),
                       _ffi.ptr(b["idx"]), self.M, _ffi.ptr(b["ns"]), _ffi.ptr(b["es"]), self.G, _ffi.ptr(b["xyz"]),
                       _ffi.ptr(self.recv), _ffi.ptr(self.send), _ffi.ptr(self.dist), _ffi.ptr(self.flags),
-                      self.flags_arg & 1, _ffi.stream())
+                      self.flags_arg & 3, _ffi.stream())
         else:
             self._prepare()
             _ffi.call("mp_sort_segments_i32", _ffi.ptr(self.recv), self.M, _ffi.ptr(self.recv_sorted),
                       _ffi.ptr(self.perm), _ffi.ptr(self.sort_ws), self.sort_ws_bytes, _ffi.stream())
             _ffi.call("mp_schnet_node_in_f32", _ffi.ptr(b["z"]), self.N, _ffi.ptr(p["embedding"]),
-                      int(p["embedding"].shape[0]), 64, _ffi.ptr(p["dense0/kernel"]), _ffi.ptr(p.get("dense0/bias")),
-                      _ffi.ptr(p["interaction0/dense1/kernel"]), _ffi.ptr(self.n), _ffi.ptr(self.x),
-                      self.flags_arg & 1, _ffi.stream())
+                      int(p["embedding"].shape[0]), 64, _ffi.ptr(w["dense0/kernel"]), _ffi.ptr(p.get("dense0/bias")),
+                      _ffi.ptr(w["interaction0/dense1/kernel"]), _ffi.ptr(self.n), _ffi.ptr(self.x),
+                      self.flags_arg & 3, _ffi.stream())
         for i in range(self.depth):
             pre = "interaction%d/" % i
             self._cfconv(i, self.agg)
             if i + 1 < self.depth:
-                _ffi.call("mp_schnet_node_update_f32", _ffi.ptr(self.agg), self.N, _ffi.ptr(p[pre + "dense2/kernel"]),
-                          _ffi.ptr(p.get(pre + "dense2/bias")), _ffi.ptr(p[pre + "dense3/kernel"]),
+                _ffi.call("mp_schnet_node_update_f32", _ffi.ptr(self.agg), self.N, _ffi.ptr(w[pre + "dense2/kernel"]),
+                          _ffi.ptr(p.get(pre + "dense2/bias")), _ffi.ptr(w[pre + "dense3/kernel"]),
                           _ffi.ptr(p.get(pre + "dense3/bias")), _ffi.ptr(self.n),
-                          _ffi.ptr(p["interaction%d/dense1/kernel" % (i + 1)]), _ffi.ptr(self.x), self.flags_arg & 1,
+                          _ffi.ptr(w["interaction%d/dense1/kernel" % (i + 1)]), _ffi.ptr(self.x), self.flags_arg & 3,
                           _ffi.stream())
             else:
-                _ffi.call("mp_schnet_node_last_f32", _ffi.ptr(self.agg), self.N, _ffi.ptr(p[pre + "dense2/kernel"]),
-                          _ffi.ptr(p.get(pre + "dense2/bias")), _ffi.ptr(p[pre + "dense3/kernel"]),
-                          _ffi.ptr(p.get(pre + "dense3/bias")), _ffi.ptr(self.n), _ffi.ptr(p["last_mlp/0/kernel"]),
-                          _ffi.ptr(p.get("last_mlp/0/bias")), _ffi.ptr(p["last_mlp/1/kernel"]),
-                          _ffi.ptr(p.get("last_mlp/1/bias")), _ffi.ptr(self.h), self.flags_arg & 1, _ffi.stream())
+                _ffi.call("mp_schnet_node_last_f32", _ffi.ptr(self.agg), self.N, _ffi.ptr(w[pre + "dense2/kernel"]),
+                          _ffi.ptr(p.get(pre + "dense2/bias")), _ffi.ptr(w[pre + "dense3/kernel"]),
+                          _ffi.ptr(p.get(pre + "dense3/bias")), _ffi.ptr(self.n), _ffi.ptr(w["last_mlp/0/kernel"]),
+                          _ffi.ptr(p.get("last_mlp/0/bias")), _ffi.ptr(w["last_mlp/1/kernel"]),
+                          _ffi.ptr(p.get("last_mlp/1/bias")), _ffi.ptr(self.h), self.flags_arg & 3, _ffi.stream())
         _ffi.call("mp_schnet_readout_f32", _ffi.ptr(self.h), _ffi.ptr(b["ns"]), self.G,
                   _ffi.ptr(p["output_mlp/0/kernel"]), _ffi.ptr(p.get("output_mlp/0/bias")),
                   _ffi.ptr(p["output_mlp/1/kernel"]), _ffi.ptr(p.get("output_mlp/1/bias")), _ffi.ptr(self.out),
                   _ffi.stream())
+
+    # ------------------------------------------------------------------------------------------------ current stream
+    def _capture(self):
+        """Capture the eight launches on this slot's private stream (a captured graph can be launched on any stream)."""
+        with torch.cuda.stream(self.stream):
+            self._launch_all()  # warm-up outside capture (lazy module load, function attributes)
+            self.stream.synchronize()
+            _ffi.call("mp_graph_begin", _ffi.stream())
+            try:
+                self._launch_all()
+            finally:
+                exe = ctypes.c_void_p()
+                _ffi.call("mp_graph_end", _ffi.stream(), ctypes.byref(exe))
+        self.graph = exe
+
+    def run_current(self, how="graph"):
+        """One forward of the bound batch on torch's CURRENT stream (ordinary stream semantics for the caller):
+        ``graph`` replays the captured forward (captured on first use), ``direct`` issues the eight launches from one
+        C-ABI call (``mp_schnet_forward_launch``), ``eager`` issues them one engine call each.  Returns this slot's
+        static ``(G', 1)`` output buffer."""
+        if how == "graph":
+            if self.graph is None:
+                torch.cuda.current_stream().synchronize()
+                self._capture()
+            _ffi.call("mp_graph_launch", self.graph, _ffi.stream())
+        elif how == "direct" and (self.sorted or self.M == 0) and self.depth <= _ffi.MP_SCHNET_MAX_DEPTH:
+            if self._desc is None:
+                self._desc = self._descriptor()
+            _ffi.call("mp_schnet_forward_launch", ctypes.byref(self._desc), _ffi.stream())
+        else:
+            self._launch_all()
+        return self.out if self.out_rows == self.G else self.out[:self.out_rows]
 
     # ------------------------------------------------------------------------------------------------ forward
     def forward(self):
@@ -193,7 +279,7 @@ class FusedSchnet:
     # ------------------------------------------------------------------------------------------------ direct launch
     def _descriptor(self):
         """``mp_schnet_forward_desc`` of the bound batch (receiver-sorted batches only)."""
-        p, b, ga = self.p, self._b, self.gauss
+        p, b, ga, w = self.p, self._b, self.gauss, self.node_images
         d = _ffi.SchnetForwardDesc()
         d.N, d.M, d.G = self.N, self.M, self.G
         d.depth, d.vocab, d.flags, d.bins = self.depth, int(p["embedding"].shape[0]), self.flags_arg, int(ga["bins"])
@@ -201,14 +287,14 @@ class FusedSchnet:
         addr = lambda t: None if t is None else t.data_ptr()
         d.numbers, d.xyz, d.idx = addr(b["z"]), addr(b["xyz"]), addr(b["idx"])
         d.node_splits, d.edge_splits = addr(b["ns"]), addr(b["es"])
-        d.embedding, d.W0, d.b0 = addr(p["embedding"]), addr(p["dense0/kernel"]), addr(p.get("dense0/bias"))
+        d.embedding, d.W0, d.b0 = addr(p["embedding"]), addr(w["dense0/kernel"]), addr(p.get("dense0/bias"))
         for i in range(self.depth):
             pre = "interaction%d/" % i
-            d.Wx[i], d.packed[i] = addr(p[pre + "dense1/kernel"]), addr(self.packed[i])
-            d.W2[i], d.b2[i] = addr(p[pre + "dense2/kernel"]), addr(p.get(pre + "dense2/bias"))
-            d.W3[i], d.b3[i] = addr(p[pre + "dense3/kernel"]), addr(p.get(pre + "dense3/bias"))
-        d.Wl0, d.bl0 = addr(p["last_mlp/0/kernel"]), addr(p.get("last_mlp/0/bias"))
-        d.Wl1, d.bl1 = addr(p["last_mlp/1/kernel"]), addr(p.get("last_mlp/1/bias"))
+            d.Wx[i], d.packed[i] = addr(w[pre + "dense1/kernel"]), addr(self.packed[i])
+            d.W2[i], d.b2[i] = addr(w[pre + "dense2/kernel"]), addr(p.get(pre + "dense2/bias"))
+            d.W3[i], d.b3[i] = addr(w[pre + "dense3/kernel"]), addr(p.get(pre + "dense3/bias"))
+        d.Wl0, d.bl0 = addr(w["last_mlp/0/kernel"]), addr(p.get("last_mlp/0/bias"))
+        d.Wl1, d.bl1 = addr(w["last_mlp/1/kernel"]), addr(p.get("last_mlp/1/bias"))
         d.Wo0, d.bo0 = addr(p["output_mlp/0/kernel"]), addr(p.get("output_mlp/0/bias"))
         d.Wo1, d.bo1 = addr(p["output_mlp/1/kernel"]), addr(p.get("output_mlp/1/bias"))
         d.recv, d.send, d.dist, d.flags_word = addr(self.recv), addr(self.send), addr(self.dist), addr(self.flags)
@@ -223,7 +309,7 @@ class FusedSchnet:
         46.6 vs 46.9 us per step) - the GPU, not the submission path, is the limit there."""
         if not (self.sorted or self.M == 0) or self.depth > _ffi.MP_SCHNET_MAX_DEPTH:
             return self.replay()
-        if self._desc is None:
+        if self._desc_ref is None:
             self._desc = self._descriptor()
             self._desc_ref = ctypes.byref(self._desc)
             self._direct = _ffi.lib().mp_schnet_forward_launch
@@ -266,3 +352,112 @@ class FusedSchnet:
                 _ffi.call("mp_graph_destroy", self.graph)
         except Exception:
             pass
+
+
+class SchnetFusedRoute:
+    """The fused forward behind ``Schnet.make_model(...)(inputs)``.
+
+    ``tensors()`` returns the model's live weight tensors under the names of ``synth.schnet_params``; the kernels read
+    them in place (the cfconv LDS images are re-packed when a weight's version counter moves).  Every distinct input
+    set - identified by the storage of its five tensors and by N, M, G - owns a batch slot (``FusedSchnet``): the first
+    call binds it (work buffers, one index pass + flag read) and issues the eight launches from one C-ABI call; from
+    the second call on the slot's captured HIP graph is replayed.  Everything is launched on torch's current stream,
+    and the returned ``(G', 1)`` tensor is a fresh copy, as a Keras model call returns a new tensor.  At most
+    ``max_slots`` batches stay bound (least recently used first out); a slot keeps its input tensors alive, which is
+    what makes their addresses an identity.
+    """
+
+    def __init__(self, tensors, depth, gauss_args, max_slots=8, fast_softplus=True, cfconv_flags=0):
+        self._tensors = tensors
+        self.depth, self.gauss = int(depth), dict(gauss_args)
+        self.max_slots, self.fast_softplus, self.cfconv_flags = int(max_slots), bool(fast_softplus), int(cfconv_flags)
+        self.mode = "auto"          # auto: direct launch on first sight, graph replay afterwards | graph | direct | eager
+        self.copy_output = True
+        self._slots = {}
+        self._p = None
+        self._wkey = None
+        self._packed = None
+        self.last = None            # how the last call ran: "direct" | "graph" | "eager"
+
+    # -- applicability of one call -----------------------------------------------------------------------------------
+    @staticmethod
+    def accepts(inputs):
+        from .autograd import needs_grad
+        from .ragged import RaggedTensor
+        if not (isinstance(inputs, (list, tuple)) and len(inputs) == 3
+                and all(isinstance(x, RaggedTensor) for x in inputs)):
+            return False
+        z, xyz, idx = (x.values for x in inputs)
+        return (z.is_cuda and z.dtype == torch.float32 and z.dim() == 1 and xyz.dtype == torch.float32
+                and xyz.dim() == 2 and int(xyz.shape[1]) == 3 and idx.dtype == torch.int64 and idx.dim() == 2
+                and int(idx.shape[1]) == 2 and z.is_contiguous() and xyz.is_contiguous() and idx.is_contiguous()
+                and int(xyz.shape[0]) == int(z.shape[0]) and inputs[0].nrows() == inputs[2].nrows()
+                and not needs_grad(z, xyz))
+
+    # -- weights ------------------------------------------------------------------------------------------------------
+    def _sync_weights(self):
+        p = self._tensors()
+        key = tuple((id(t), t._version) for t in p.values() if t is not None)
+        if key == self._wkey:
+            return
+        moved = self._wkey is None or tuple(k[0] for k in key) != tuple(k[0] for k in self._wkey)
+        torch.cuda.synchronize()   # forwards in flight still read the old images
+        if moved:                  # other tensors: every bound slot (descriptor, graph) points at the old ones
+            self._slots.clear()
+            self._p = {k: v for k, v in p.items() if v is not None}
+            self._packed = pack_weights(self._p, self.depth, int(self.gauss["bins"]))
+        else:                      # same tensors, new values: re-fill the images the graphs already point at
+            pack_weights(self._p, self.depth, int(self.gauss["bins"]), out=self._packed)
+        self._wkey = key
+
+    # -- batch slots --------------------------------------------------------------------------------------------------
+    @staticmethod
+    def _key(node, xyz, idx):
+        return (node.values.data_ptr(), xyz.values.data_ptr(), idx.values.data_ptr(), node.row_splits.data_ptr(),
+                idx.row_splits.data_ptr(), int(node.values.shape[0]), int(idx.values.shape[0]), node.nrows(),
+                idx.values._version, idx.row_splits._version, node.row_splits._version)
+
+    def _bind(self, node, xyz, idx):
+        slot = FusedSchnet(self._p, depth=self.depth, gauss_args=self.gauss, fast_softplus=self.fast_softplus,
+                           cfconv_flags=self.cfconv_flags, packed=self._packed)
+        batch = {"z": node.values, "xyz": xyz.values, "idx": idx.values, "ns": node.row_splits, "es": idx.row_splits,
+                 "ns_host": node.row_splits_host()}
+        known = None
+        for plan in idx._plans.values():   # a producer (host packer, on-GPU SetRange) may have classified the list already
+            if plan._flags_host is not None:
+                known = plan._flags_host
+        slot.bind(batch, int(node.values.shape[0]), int(idx.values.shape[0]), node.nrows(), known_flags=known)
+        slot.calls = 0
+        return slot
+
+    def __call__(self, inputs):
+        node, xyz, idx = inputs
+        self._sync_weights()
+        key = self._key(node, xyz, idx)
+        slot = self._slots.get(key)
+        if slot is None:
+            slot = self._bind(node, xyz, idx)
+            while len(self._slots) >= self.max_slots:
+                self._slots.pop(next(iter(self._slots)))
+            self._slots[key] = slot
+        elif next(reversed(self._slots)) != key:   # keep the dictionary in least-recently-used order
+            self._slots[key] = self._slots.pop(key)
+        slot.calls += 1
+        how = self.mode
+        if how == "auto":
+            how = "direct" if slot.calls == 1 else "graph"
+        out = slot.run_current(how)
+        self.last = how
+        return out.clone() if self.copy_output else out
+
+    def slot_of(self, inputs):
+        return self._slots.get(self._key(*inputs))
+
+    def check_flags(self):
+        for slot in self._slots.values():
+            slot.check_flags()
+
+    def release(self):
+        """Unbind every batch (frees the work buffers and the references to the input tensors)."""
+        torch.cuda.synchronize()
+        self._slots.clear()

@@ -44,6 +44,23 @@ class SetRange:
             return {self._config_kwargs["range_indices"]: idx, self._config_kwargs["range_attributes"]: attr}
         return self._run(node_coordinates)
 
+    def count_edges(self, node_coordinates: RaggedTensor):
+        """Pass 1 alone: the int64 edge row_splits ``(G+1)`` the rule produces for this batch (device tensor).  Used to
+        balance graph shards by edge count before any edge list exists (gcnn_keras_amd/sharding.py)."""
+        xyz = node_coordinates.values.contiguous()
+        _ffi.require_device(xyz, node_coordinates.row_splits)
+        n, g = int(xyz.shape[0]), node_coordinates.nrows()
+        md = -1.0 if self.max_distance is None else float(self.max_distance)
+        mn = -1 if self.max_neighbours is None else int(min(self.max_neighbours, 2 ** 30))
+        nbytes = ctypes.c_size_t(0)
+        _ffi.call("mp_radius_graph_workspace_bytes", n, ctypes.byref(nbytes))
+        ws = torch.empty(max(nbytes.value, 1), dtype=torch.uint8, device=xyz.device)
+        node_ptr = torch.empty(n + 1, dtype=torch.int32, device=xyz.device)
+        edge_splits = torch.empty(g + 1, dtype=torch.int64, device=xyz.device)
+        _ffi.call("mp_radius_graph_count_f32", _ffi.ptr(xyz), _ffi.ptr(node_coordinates.row_splits), g, n, md, mn,
+                  _ffi.ptr(node_ptr), _ffi.ptr(edge_splits), _ffi.ptr(ws), nbytes.value, _ffi.stream())
+        return edge_splits
+
     def _run(self, node_coordinates: RaggedTensor):
         """``node_coordinates``: ragged ``(batch, [N], 3)`` float32.  Returns ``(range_indices, range_attributes)``:
         ragged ``(batch, [M], 2)`` int64 sample indices and ragged ``(batch, [M], 1)`` distances; the returned index

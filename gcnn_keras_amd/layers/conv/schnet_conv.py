@@ -143,6 +143,19 @@ class SchNetInteraction(GraphBaseLayer):
         r"""inputs: ``[nodes, edges, tensor_index]`` -> updated nodes ``(batch,[N],F)`` (schnet_conv.py:159-165)."""
         node, edge, indexlist = inputs
         update = self.lay_cfconv([self.lay_dense1(node, **kwargs), edge, indexlist], **kwargs)
+        nv, uv = node.values, update.values
+        if (self.units == 128 and self.lay_dense2.activation in _SSP_NAMES and nv.dim() == 2 and uv.dim() == 2
+                and tuple(nv.shape) == tuple(uv.shape) and int(nv.shape[1]) == 128 and nv.dtype == torch.float32
+                and not needs_grad(nv, uv)):
+            # node side in ONE kernel (csrc/mp_schnet_node.hip, 16-node tiles, both 128x128 GEMMs on FP32 MFMA with the
+            # hidden tile handed over in LDS, residual add in the epilogue) instead of Dense, Dense, LazyAdd
+            _ffi.require_device(nv, uv)
+            out = torch.empty_like(nv)
+            _ffi.call("mp_schnet_node_residual_f32", _ffi.ptr(uv.contiguous()), int(nv.shape[0]),
+                      _ffi.ptr(self.lay_dense2.kernel), _ffi.ptr(self.lay_dense2.bias),
+                      _ffi.ptr(self.lay_dense3.kernel), _ffi.ptr(self.lay_dense3.bias), _ffi.ptr(nv.contiguous()),
+                      _ffi.ptr(out), 0, _ffi.stream())
+            return node.with_values(out)
         update = self.lay_dense3(self.lay_dense2(update, **kwargs), **kwargs)
         return self.lay_add([node, update], **kwargs)
 

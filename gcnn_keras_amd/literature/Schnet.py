@@ -2,7 +2,10 @@
 
 ``make_model(**kwargs)`` accepts the reference's keyword dictionary (validated against ``model_default`` by
 ``update_model_kwargs``) and returns a callable model taking ``[node_attributes, node_coordinates, edge_indices]``
-as ragged tensors.  Weights are created in constructor order, so ``model.set_weights`` accepts the list that
+as ragged tensors.  Configurations that fit the fused kernels (``gcnn_keras_amd.fused.supports``: the reference's
+defaults at any depth) run the whole forward in eight HIP kernels on the model's own weight tensors
+(``model.fused``: the route object - launch mode, bound batches); everything else, and any call that asks for
+gradients, runs the reference's layer sequence op by op.  Weights are created in constructor order, so ``model.set_weights`` accepts the list that
 ``gcnn_keras_amd.synth.schnet_params`` / a Keras ``get_weights()`` of the reference model produce.
 """
 from ..layers.casting import ChangeTensorType
@@ -11,6 +14,7 @@ from ..layers.geom import GaussBasisLayer, NodeDistanceEuclidean, NodePosition
 from ..layers.mlp import MLP, GraphMLP
 from ..layers.modules import Dense, OptionalInputEmbedding
 from ..layers.pooling import PoolingNodes
+from .. import fused as _fused
 from ..model.utils import Model, update_model_kwargs
 
 __model_version__ = "2022.11.25"
@@ -63,7 +67,14 @@ def make_model(inputs: list = None, input_embedding: dict = None, make_distance:
     cast = ChangeTensorType(input_tensor_type="ragged", output_tensor_type="tensor") \
         if (output_embedding == "node" and output_to_tensor) else None
 
-    def forward(model_inputs, **kwargs):
+    def forward(model_inputs, fused=None, **kwargs):
+        # Fused route (csrc/mp_schnet_node.hip, mp_cfconv.hip: stage 0, depth x (cfconv + node chain), readout = 8 kernels,
+        # graph-replayed for a re-bound batch) whenever configuration and inputs fit it and no gradient is requested;
+        # ``fused=False`` forces the layer path below, ``fused=True`` insists on the kernels.
+        if route is not None and fused is not False and route.accepts(model_inputs):
+            return route(model_inputs)
+        if fused is True:
+            raise ValueError("this Schnet configuration / these inputs do not fit the fused kernels")
         node_input, xyz_input, edge_index_input = model_inputs
         n = embed(node_input)
         edi = edge_index_input
@@ -103,10 +114,34 @@ def make_model(inputs: list = None, input_embedding: dict = None, make_distance:
     if out_mlp is not None:
         out_mlp.ensure_built((None, last_dim) if output_embedding == "graph" else (None, None, last_dim))
     layers = [embed, dense0] + interactions + [last] + ([out_mlp] if out_mlp is not None else [])
+
+    def fused_tensors():
+        """The model's live weight tensors under the names the fused kernels' host side uses (synth.schnet_params)."""
+        p = {"embedding": embed.embeddings, "dense0/kernel": dense0.kernel, "dense0/bias": dense0.bias}
+        for i, inter in enumerate(interactions):
+            pre, cf = "interaction%d/" % i, inter.lay_cfconv
+            p[pre + "cfconv/dense1/kernel"], p[pre + "cfconv/dense1/bias"] = cf.lay_dense1.kernel, cf.lay_dense1.bias
+            p[pre + "cfconv/dense2/kernel"], p[pre + "cfconv/dense2/bias"] = cf.lay_dense2.kernel, cf.lay_dense2.bias
+            p[pre + "dense1/kernel"] = inter.lay_dense1.kernel
+            p[pre + "dense2/kernel"], p[pre + "dense2/bias"] = inter.lay_dense2.kernel, inter.lay_dense2.bias
+            p[pre + "dense3/kernel"], p[pre + "dense3/bias"] = inter.lay_dense3.kernel, inter.lay_dense3.bias
+        for name, mlp in (("last_mlp", last), ("output_mlp", out_mlp)):
+            for k, d in enumerate(mlp.mlp_dense_layer_list):
+                p["%s/%d/kernel" % (name, k)], p["%s/%d/bias" % (name, k)] = d.kernel, d.bias
+        return p
+
+    merged = {"inputs": inputs, "input_embedding": input_embedding, "make_distance": make_distance,
+              "expand_distance": expand_distance, "gauss_args": gauss_args, "interaction_args": interaction_args,
+              "node_pooling_args": node_pooling_args, "depth": depth, "last_mlp": last_mlp,
+              "output_embedding": output_embedding, "use_output_mlp": use_output_mlp, "output_mlp": output_mlp}
+    route = None
+    if _fused.supports(merged) and embed.use_embedding:
+        route = _fused.SchnetFusedRoute(fused_tensors, depth, gauss_args)
     model = Model(name, forward, layers, config={"depth": depth, "interaction_args": interaction_args,
                                                   "gauss_args": gauss_args, "last_mlp": last_mlp,
                                                   "output_mlp": output_mlp, "node_pooling_args": node_pooling_args,
                                                   "input_embedding": input_embedding,
                                                   "output_embedding": output_embedding})
     model.__kgcnn_model_version__ = __model_version__
+    model.fused = route   # None: this configuration always runs the layer path
     return model

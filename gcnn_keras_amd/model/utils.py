@@ -1,5 +1,13 @@
-"""Model keyword handling (mirror of kgcnn/model/utils.py:69-142): nested merge of user kwargs into the model
-defaults, used as ``@update_model_kwargs(model_default)`` on every ``make_model``."""
+"""Model keyword handling with the contract of kgcnn/model/utils.py:69-142 (written independently of it):
+
+* ``update_model_kwargs_logic(defaults, user, update_recursive)`` returns a fresh dictionary = deep copy of the defaults
+  overlaid with the user's entries; a top-level user key that the defaults do not know raises ``ValueError``; where both
+  sides hold a dictionary the overlay recurses (``update_recursive`` levels deep, below that it replaces wholesale); a
+  dictionary replaced by a non-dictionary, and a nested key the defaults lack, are accepted with a warning.
+* ``@update_model_kwargs(model_default)`` applies that to the keyword arguments of a ``make_model`` and, like the
+  reference, takes the logger level from the merged ``verbose`` entry; positional arguments pass through untouched
+  (with an error log, since they cannot be merged).
+"""
 import copy
 import functools
 import logging
@@ -9,49 +17,45 @@ module_logger = logging.getLogger(__name__)
 module_logger.setLevel(logging.WARNING)
 
 
+def _overlay(base, patch, levels_left):
+    """Write ``patch`` over ``base`` in place; ``levels_left`` counts how many more dictionary levels may be merged
+    rather than replaced."""
+    for name, new_value in patch.items():
+        old_value = base.get(name, _overlay)        # the function object doubles as the 'absent' marker
+        if old_value is _overlay:
+            module_logger.warning("Model kwargs: Unknown key %s with value %s", name, new_value)
+            base[name] = new_value
+        elif isinstance(old_value, dict) and isinstance(new_value, dict) and levels_left > 0:
+            _overlay(old_value, new_value, levels_left - 1)
+        else:
+            if isinstance(old_value, dict) and not isinstance(new_value, dict):
+                module_logger.warning("Model kwargs: Overwriting dictionary of %s with %s", name, new_value)
+            base[name] = new_value
+    return base
+
+
 def update_model_kwargs_logic(default_kwargs: dict = None, user_kwargs: dict = None, update_recursive=inf):
-    out = {}
-    if default_kwargs is None:
-        default_kwargs = {}
-    if user_kwargs is None:
-        user_kwargs = {}
-    for iter_key in user_kwargs.keys():
-        if iter_key not in default_kwargs:
-            raise ValueError("Model kwarg {0} not in default arguments {1}".format(iter_key, default_kwargs.keys()))
-    out.update(copy.deepcopy(default_kwargs))
-
-    def _nested_update(dict1, dict2, max_depth=inf, depth=0):
-        for key, values in dict2.items():
-            if key not in dict1:
-                module_logger.warning("Model kwargs: Unknown key {0} with value {1}".format(key, values))
-                dict1[key] = values
-                continue
-            if not isinstance(dict1[key], dict):
-                dict1[key] = values
-                continue
-            if not isinstance(values, dict):
-                module_logger.warning("Model kwargs: Overwriting dictionary of {0} with {1}".format(key, values))
-                dict1[key] = values
-                continue
-            if depth < max_depth:
-                dict1[key] = _nested_update(dict1[key], values, max_depth=max_depth, depth=depth + 1)
-            else:
-                dict1[key] = values
-        return dict1
-
-    return _nested_update(out, user_kwargs, update_recursive, 0)
+    defaults = default_kwargs or {}
+    user = user_kwargs or {}
+    unknown = [name for name in user if name not in defaults]
+    if unknown:
+        raise ValueError("Model kwarg %s not in default arguments %s" % (unknown[0], list(defaults)))
+    return _overlay(copy.deepcopy(defaults), user, update_recursive)
 
 
 def update_model_kwargs(model_default, update_recursive=inf):
-    def model_update_decorator(func):
-        @functools.wraps(func)
-        def update_wrapper(*args, **kwargs):
-            updated_kwargs = update_model_kwargs_logic(model_default, kwargs, update_recursive)
-            if len(args) > 0:
-                module_logger.error("Can only update kwargs, not %s" % args)
-            return func(*args, **updated_kwargs)
-        return update_wrapper
-    return model_update_decorator
+    def decorate(make_model):
+        @functools.wraps(make_model)
+        def with_defaults(*args, **kwargs):
+            merged = update_model_kwargs_logic(model_default, kwargs, update_recursive)
+            if "verbose" in merged:
+                module_logger.setLevel(merged["verbose"])
+            module_logger.info("Updated model kwargs: %s", merged)
+            if args:
+                module_logger.error("Can only update kwargs, not %s", args)
+            return make_model(*args, **merged)
+        return with_defaults
+    return decorate
 
 
 class Model:

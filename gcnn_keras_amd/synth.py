@@ -41,6 +41,24 @@ def _splits(lengths):
     return np.concatenate([np.zeros(1, np.int64), np.cumsum(np.asarray(lengths, dtype=np.int64))])
 
 
+def qm9_like_nodes(num_graphs=128, seed=1234, sigma=1.6):
+    """Node side of :func:`qm9_like_batch` alone (same draws): numbers, coordinates and node row_splits.  The edge lists
+    of large batches (BASELINE config 4: 100 000 molecules) are then built on the GPU by the engine's ``SetRange``
+    (gcnn_keras_amd/graph/preprocessor.py), which applies the same rule as :func:`radius_graph`."""
+    rng = np.random.default_rng(seed)
+    rng_z = np.random.default_rng(seed + 1)
+    z_vals = np.array([1, 6, 7, 8, 9], dtype=np.float32)
+    z_p = np.array([.51, .35, .06, .07, .01])
+    zs, xs, n_len = [], [], []
+    for _ in range(num_graphs):
+        n = int(np.clip(np.rint(rng.normal(18.0, 4.5)), 3, 29))
+        xs.append(rng.normal(0.0, sigma, size=(n, 3)).astype(np.float32))
+        zs.append(rng_z.choice(z_vals, size=n, p=z_p).astype(np.float32))
+        n_len.append(n)
+    return {"node_number": np.concatenate(zs), "node_coordinates": np.concatenate(xs, axis=0),
+            "node_splits": _splits(n_len)}
+
+
 def qm9_like_batch(num_graphs=128, seed=1234, sigma=1.6, max_distance=4.0, max_neighbours=30):
     """BASELINE config 2: QM9-shaped molecules.
 
@@ -49,22 +67,13 @@ def qm9_like_batch(num_graphs=128, seed=1234, sigma=1.6, max_distance=4.0, max_n
     draw order per graph: n_g, then xyz (as in BASELINE.md's calibration: seed 1234 -> N=2301, M=26190);
     Z comes from a second stream (seed + 1).  Returns a dict of flat values + int64 row_splits.
     """
-    rng = np.random.default_rng(seed)
-    rng_z = np.random.default_rng(seed + 1)
-    z_vals = np.array([1, 6, 7, 8, 9], dtype=np.float32)
-    z_p = np.array([.51, .35, .06, .07, .01])
-    zs, xs, es, n_len, e_len = [], [], [], [], []
-    for _ in range(num_graphs):
-        n = int(np.clip(np.rint(rng.normal(18.0, 4.5)), 3, 29))
-        xyz = rng.normal(0.0, sigma, size=(n, 3)).astype(np.float32)
-        z = rng_z.choice(z_vals, size=n, p=z_p).astype(np.float32)
-        ei = radius_graph(xyz, max_distance=max_distance, max_neighbours=max_neighbours)
-        zs.append(z); xs.append(xyz); es.append(ei); n_len.append(n); e_len.append(len(ei))
-    return {
-        "node_number": np.concatenate(zs), "node_coordinates": np.concatenate(xs, axis=0),
-        "edge_indices": np.concatenate(es, axis=0).reshape(-1, 2).astype(np.int64),
-        "node_splits": _splits(n_len), "edge_splits": _splits(e_len),
-    }
+    out = qm9_like_nodes(num_graphs, seed, sigma)
+    ns = out["node_splits"]
+    es = [radius_graph(out["node_coordinates"][ns[g]:ns[g + 1]], max_distance=max_distance,
+                       max_neighbours=max_neighbours) for g in range(num_graphs)]
+    out["edge_indices"] = np.concatenate(es, axis=0).reshape(-1, 2).astype(np.int64)
+    out["edge_splits"] = _splits([len(e) for e in es])
+    return out
 
 
 ASPIRIN_Z = np.array([6] * 9 + [1] * 8 + [8] * 4, dtype=np.float32)  # C9 H8 O4

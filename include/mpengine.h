@@ -218,6 +218,21 @@ int mp_cfconv_gauss_fused_f32(const float* x, int64_t N, const float* dist, int 
                               float offset, const float* packed, const int32_t* recv_sorted, const int32_t* send,
                               const int32_t* perm, int64_t M, int flags, float* out_zeroed, mpStream_t stream);
 
+/* The same two entry points with a caller workspace, which flags bit 5 (value 32) needs: DETERMINISTIC mode.  The partial
+ * sums of every tile's first and last segment (the ones that may continue in a neighbouring 32-edge tile) are then not
+ * added to `out` with float atomics but parked in the workspace and added per receiver, in edge order, by a second small
+ * kernel: bit-identical results from run to run also for receivers with more than 32 incoming edges (the default mode can
+ * differ there in the last bit, float atomics arrive in any order).  Costs one extra launch and 1 KB of workspace per tile;
+ * without bit 5 the workspace is ignored (NULL allowed). */
+int mp_cfconv_det_workspace_bytes(int64_t M, size_t* bytes_out_host);
+int mp_cfconv_fused_ws_f32(const float* x, int64_t N, const float* rbf, int B, const float* packed,
+                           const int32_t* recv_sorted, const int32_t* send, const int32_t* perm, int64_t M, int flags,
+                           float* out_zeroed, void* ws, size_t ws_bytes, mpStream_t stream);
+int mp_cfconv_gauss_fused_ws_f32(const float* x, int64_t N, const float* dist, int bins, float distance, float sigma,
+                                 float offset, const float* packed, const int32_t* recv_sorted, const int32_t* send,
+                                 const int32_t* perm, int64_t M, int flags, float* out_zeroed, void* ws, size_t ws_bytes,
+                                 mpStream_t stream);
+
 /* Diagnostic build of mp_cfconv_gauss_fused_f32 (20 bins, fast softplus): adds per-phase shader-cycle sums into
  * diag8 (8 x uint64, caller-zeroed): [0] weight staging, [1] tile setup + Gauss basis, [2] GEMM1, [3] softplus +
  * sender-row loads issued, [4] GEMM2, [5] multiply + slab write, [6] slab read, [7] segmented sum + stores/atomics.
@@ -241,7 +256,15 @@ int mp_painn_message_fused_f32(const float* s, const float* v, int64_t N, const 
  * node_update: n += ssp(agg W2 + b2) W3 + b3 ; x = n Wx_next ; agg := 0
  * node_last:   n' = n + ssp(agg W2 + b2) W3 + b3 ; h = ssp(ssp(n' Wl0 + bl0) Wl1 + bl1) (N,64) ; agg := 0
  * readout:     out[g] = ssp(sum_{nodes of g} h W_o0 + b_o0) W_o1 + b_o1   (PoolingNodes(sum) + MLP([64,1]))
- * flags bit0: fast softplus as in mp_cfconv_fused_f32. */
+ * flags bit0: fast softplus as in mp_cfconv_fused_f32; bit1: every weight-matrix pointer is an
+ * mp_schnet_node_pack_f32 image of the Keras kernel instead of the kernel itself (biases stay plain): the image stores,
+ * per wave and lane, the registers of four consecutive k-steps as one float4, so a workgroup loads its weight slices
+ * with 16-B instead of strided 4-B reads. */
+int mp_schnet_node_pack_f32(const float* W, int K, int U, float* packed /* K*U floats */, mpStream_t stream);
+/* SchNetInteraction.call's node side alone (schnet_conv.py:162-164), out of place, for the layer API:
+ * n_out = n_in + Dense(lin)(Dense(ssp)(agg)); agg is left untouched. */
+int mp_schnet_node_residual_f32(const float* agg, int64_t N, const float* W2, const float* b2, const float* W3,
+                                const float* b3, const float* n_in, float* n_out, int flags, mpStream_t stream);
 int mp_schnet_node_in_f32(const float* numbers, int64_t N, const float* emb, int vocab, int emb_dim, const float* W0,
                           const float* b0, const float* Wx, float* n_out, float* x_out, int flags, mpStream_t stream);
 /* mp_schnet_node_in_f32 and mp_edge_prepare_i64_f32 in ONE launch (disjoint workgroups): they are independent and at
@@ -293,8 +316,8 @@ int mp_cos_cutoff_grad_f32(const float* d, int64_t n, float cutoff, const float*
 /* The whole fused forward (kgcnn/literature/Schnet.py:104-148 with receiver-sorted edges) as ONE call: stage 0,
  * depth x (cfconv + node update), last node chain, readout, launched in sequence on `stream` from a descriptor of the
  * bound batch slot.  Equivalent to replaying a captured HIP graph of the same eight launches, without the capture:
- * the entry for batches whose shapes change from call to call.  flags: bit0 fast softplus, bits 2-4 as
- * mp_cfconv_fused_f32. */
+ * the entry for batches whose shapes change from call to call.  flags: bit0 fast softplus, bit1 node-side
+ * weight pointers (W0, Wx, W2, W3, Wl0, Wl1) are mp_schnet_node_pack_f32 images, bits 2-4 as mp_cfconv_fused_f32. */
 #define MP_SCHNET_MAX_DEPTH 8
 typedef struct mp_schnet_forward_desc {
   int64_t N, M, G;

@@ -58,22 +58,49 @@ static void gather_rows(const float* x, int64_t F, const int64_t* shifted, int c
   for (int64_t e = 0; e < M; ++e) memcpy(out + e * F, x + shifted[2 * e + col] * F, sizeof(float) * (size_t)F);
 }
 
-/* Keras Dense: out = act(x @ W + b), W (K,U) row-major */
+/* Keras Dense: out = act(x @ W + b), W (K,U) row-major.  Register-tiled (4 rows x 32 columns of accumulators, the
+ * k loop innermost over them) so that the baseline is a fair CPU GEMM and not a memory-bound triple loop; every output
+ * element is still one k-ordered chain of multiply-adds, i.e. the same bits as the plain loop. */
+#define DR 4
+#define DC 32
 static void dense(const float* x, int64_t R, int64_t K, const float* W, const float* b, int64_t U, int act,
                   float* out) {
+  const int64_t rblocks = (R + DR - 1) / DR;
 #pragma omp parallel for schedule(static)
-  for (int64_t r = 0; r < R; ++r) {
-    float* o = out + r * U;
-    for (int64_t u = 0; u < U; ++u) o[u] = 0.0f;
-    const float* xr = x + r * K;
-    for (int64_t k = 0; k < K; ++k) {
-      const float xv = xr[k];
-      const float* w = W + k * U;
-      for (int64_t u = 0; u < U; ++u) o[u] += xv * w[u];
-    }
-    for (int64_t u = 0; u < U; ++u) {
-      float v = o[u] + (b ? b[u] : 0.0f);
-      o[u] = act == ACT_SSP ? ssp(v) : v;
+  for (int64_t rb = 0; rb < rblocks; ++rb) {
+    const int64_t r0 = rb * DR;
+    const int nr = (int)((R - r0) < DR ? (R - r0) : DR);
+    for (int64_t c0 = 0; c0 < U; c0 += DC) {
+      const int nc = (int)((U - c0) < DC ? (U - c0) : DC);
+      float acc[DR][DC];
+      for (int r = 0; r < DR; ++r)
+        for (int c = 0; c < DC; ++c) acc[r][c] = 0.0f;
+      if (nr == DR && nc == DC) {
+        const float* x0 = x + (r0 + 0) * K; const float* x1 = x + (r0 + 1) * K;
+        const float* x2 = x + (r0 + 2) * K; const float* x3 = x + (r0 + 3) * K;
+        for (int64_t k = 0; k < K; ++k) {
+          const float* w = W + k * U + c0;
+          const float a0 = x0[k], a1 = x1[k], a2 = x2[k], a3 = x3[k];
+          for (int c = 0; c < DC; ++c) {
+            acc[0][c] += a0 * w[c]; acc[1][c] += a1 * w[c]; acc[2][c] += a2 * w[c]; acc[3][c] += a3 * w[c];
+          }
+        }
+      } else {
+        for (int64_t k = 0; k < K; ++k) {
+          const float* w = W + k * U + c0;
+          for (int r = 0; r < nr; ++r) {
+            const float a = x[(r0 + r) * K + k];
+            for (int c = 0; c < nc; ++c) acc[r][c] += a * w[c];
+          }
+        }
+      }
+      for (int r = 0; r < nr; ++r) {
+        float* o = out + (r0 + r) * U + c0;
+        for (int c = 0; c < nc; ++c) {
+          const float v = acc[r][c] + (b ? b[c0 + c] : 0.0f);
+          o[c] = act == ACT_SSP ? ssp(v) : v;
+        }
+      }
     }
   }
 }

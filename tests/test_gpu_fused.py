@@ -5,12 +5,14 @@ import torch
 
 from gcnn_keras_amd import synth
 from oracle import kgcnn_oracle as ko
+from parity import assert_rows_close, rowwise_rel
 
 pytestmark = pytest.mark.gpu
 
 
 def _rel_err(got, ref):
-    return float(np.max(np.abs(got - ref))) / max(float(np.max(np.abs(ref))), 1e-30)
+    """Per-ROW relative error (tests/parity.py): every node / graph row is held to the bar on its own magnitude."""
+    return rowwise_rel(got, ref)
 
 
 def _cfconv_case(seed, num_graphs=9, shuffle=False):
@@ -104,6 +106,92 @@ def test_cfconv_high_in_degree_segments_span_many_tiles(flags):
     assert _rel_err(got, ref) <= 1e-5
     isolated = [r for r in range(n) if r not in degrees]
     assert np.all(got[isolated] == 0.0)                       # has_unconnected pad, kgcnn/layers/pooling.py:74-76
+
+
+def _high_degree_case(seed=4):
+    rng = np.random.default_rng(seed)
+    n = 40
+    degrees = {0: 1, 3: 100, 4: 33, 9: 64, 17: 7, 39: 70}          # receiver -> in-degree; everything else isolated
+    recv = np.concatenate([np.full(d, r) for r, d in sorted(degrees.items())])
+    send = rng.integers(0, n, size=len(recv))
+    idx = np.stack([recv, send], axis=1).astype(np.int64)
+    m = len(idx)
+    ns, es = np.array([0, n], dtype=np.int64), np.array([0, m], dtype=np.int64)
+    x = ko.R(rng.normal(size=(n, 128)).astype(np.float32), ns)
+    dist = ko.R(rng.uniform(0.5, 4.0, size=(m, 1)).astype(np.float32), es)
+    rbf = ko.gauss_basis(dist, 20, 4.0, 0.4)
+    p = {"dense1/kernel": synth.glorot_uniform(rng, 20, 128), "dense1/bias": rng.uniform(-.1, .1, 128).astype(np.float32),
+         "dense2/kernel": synth.glorot_uniform(rng, 128, 128),
+         "dense2/bias": rng.uniform(-.1, .1, 128).astype(np.float32)}
+    ref = ko.schnet_cfconv(x, rbf, ko.R(idx, es), p).values
+    ref64 = ko.schnet_cfconv(ko.to_dtype(x, np.float64), ko.to_dtype(rbf, np.float64), ko.R(idx, es),
+                             ko.to_dtype(p, np.float64)).values
+    return n, m, recv, send, x, dist, p, ref, ref64
+
+
+@pytest.mark.parametrize("flags", [33, 37, 49, 32])
+def test_cfconv_deterministic_mode_is_bit_reproducible(flags):
+    """flags bit 5: boundary partials are parked in a workspace and added per receiver in edge order by a second kernel
+    (no float atomics).  Receivers with 33..100 incoming edges span several 32-edge tiles - the case where the default mode
+    may differ in the last bit between runs; here repeated launches must agree bit for bit, and every row holds the 1e-5 bar."""
+    import ctypes
+    from gcnn_keras_amd import _ffi
+    n, m, recv, send, x, dist, p, ref, ref64 = _high_degree_case()
+    w = {k: torch.from_numpy(v).cuda() for k, v in p.items()}
+    packed = torch.empty(_ffi.lib().mp_cfconv_packed_floats(), dtype=torch.float32, device="cuda")
+    _ffi.call("mp_cfconv_pack_f32", _ffi.ptr(w["dense1/kernel"]), _ffi.ptr(w["dense1/bias"]), 20,
+              _ffi.ptr(w["dense2/kernel"]), _ffi.ptr(w["dense2/bias"]), _ffi.ptr(packed), _ffi.stream())
+    nbytes = ctypes.c_size_t(0)
+    _ffi.call("mp_cfconv_det_workspace_bytes", m, ctypes.byref(nbytes))
+    ws = torch.empty(nbytes.value, dtype=torch.uint8, device="cuda")
+    dx, dd = torch.from_numpy(x.values).cuda(), torch.from_numpy(dist.values.reshape(-1)).cuda()
+    dr, dsnd = torch.from_numpy(recv.astype(np.int32)).cuda(), torch.from_numpy(send.astype(np.int32)).cuda()
+    outs = []
+    for _ in range(4):
+        out = torch.zeros((n, 128), dtype=torch.float32, device="cuda")
+        _ffi.call("mp_cfconv_gauss_fused_ws_f32", _ffi.ptr(dx), n, _ffi.ptr(dd), 20, 4.0, 0.4, 0.0, _ffi.ptr(packed),
+                  _ffi.ptr(dr), _ffi.ptr(dsnd), None, m, flags, _ffi.ptr(out), _ffi.ptr(ws), nbytes.value, _ffi.stream())
+        outs.append(out.clone())
+    torch.cuda.synchronize()
+    assert all(torch.equal(outs[0], o) for o in outs[1:])
+    assert_rows_close(outs[0].cpu().numpy(), ref, ref64, what="deterministic cfconv")
+    # without the workspace the flag is refused rather than silently ignored
+    assert _ffi.lib().mp_cfconv_gauss_fused_ws_f32(_ffi.ptr(dx), n, _ffi.ptr(dd), 20, 4.0, 0.4, 0.0, _ffi.ptr(packed),
+                                                   _ffi.ptr(dr), _ffi.ptr(dsnd), None, m, flags,
+                                                   _ffi.ptr(outs[0]), None, 0, _ffi.stream()) == _ffi.MP_EINVAL
+
+
+def test_cfconv_deterministic_mode_on_a_real_batch_matches_default_mode():
+    """On a QM9-shaped batch (in-degree <= 30) both modes must give the same bits: there every boundary receiver gets at
+    most two partials, and a + b == b + a."""
+    import ctypes
+    from gcnn_keras_amd import _ffi
+    from gcnn_keras_amd.ragged import RaggedTensor
+    b, x, ridx, dist, rbf, p = _cfconv_case(5, num_graphs=40)
+    dx = RaggedTensor.from_numpy(x.values, x.row_splits)
+    di = RaggedTensor.from_numpy(ridx.values, ridx.row_splits)
+    plan = di.index_plan(dx)
+    _, perm, seg = plan.csr(0)
+    assert perm is None
+    n, m = plan.N, plan.M
+    w = {k: torch.from_numpy(v).cuda() for k, v in p.items()}
+    packed = torch.empty(_ffi.lib().mp_cfconv_packed_floats(), dtype=torch.float32, device="cuda")
+    _ffi.call("mp_cfconv_pack_f32", _ffi.ptr(w["dense1/kernel"]), _ffi.ptr(w["dense1/bias"]), 20,
+              _ffi.ptr(w["dense2/kernel"]), _ffi.ptr(w["dense2/bias"]), _ffi.ptr(packed), _ffi.stream())
+    nbytes = ctypes.c_size_t(0)
+    _ffi.call("mp_cfconv_det_workspace_bytes", m, ctypes.byref(nbytes))
+    ws = torch.empty(nbytes.value, dtype=torch.uint8, device="cuda")
+    e = torch.from_numpy(dist.values.reshape(-1)).cuda()
+    outs = {}
+    for flags in (1, 33):
+        out = torch.zeros((n, 128), dtype=torch.float32, device="cuda")
+        _ffi.call("mp_cfconv_gauss_fused_ws_f32", _ffi.ptr(dx.values), n, _ffi.ptr(e), 20, 4.0, 0.4, 0.0,
+                  _ffi.ptr(packed), _ffi.ptr(seg.contiguous()), _ffi.ptr(plan.col(1).contiguous()), None, m, flags,
+                  _ffi.ptr(out), _ffi.ptr(ws), nbytes.value, _ffi.stream())
+        outs[flags] = out
+    torch.cuda.synchronize()
+    assert torch.equal(outs[1], outs[33])
+    assert_rows_close(outs[33].cpu().numpy(), ko.schnet_cfconv(x, rbf, ridx, p).values, what="det cfconv, QM9 batch")
 
 
 def test_cfconv_no_bias_and_argument_checks():

@@ -67,6 +67,44 @@ def test_model_on_packed_batches_double_buffered():
         assert np.array_equal(got, ref)
 
 
+def test_batches_run_ahead_without_host_sync():
+    """The documented serving loop: pack batch k+1, k+2, ... while earlier batches compute, no host synchronisation and
+    every batch dropped right after its call.  ``PackedBatch.wait`` registers the batch's tensors with the consumer
+    stream, so the allocator cannot recycle a dropped batch's blocks for a later pack() while kernels of that batch are
+    still queued.  Results must equal the synchronous ones bit for bit."""
+    from gcnn_keras_amd.data import BatchPacker
+    from gcnn_keras_amd.literature import Schnet
+    p = synth.schnet_params(seed=7, random_bias=True)
+    model = Schnet.make_model(depth=3)
+    model.set_weights(list(p.values()))
+    model.fused.max_slots = 1                              # every new batch evicts (and frees) the previous slot
+    rng = np.random.default_rng(0)
+    batches = [synth.qm9_like_batch(num_graphs=int(rng.integers(40, 90)), seed=100 + k) for k in range(12)]
+    graphs = [_graphs(b) for b in batches]
+    # synchronous reference
+    packer = BatchPacker(ITEMS, index_item="edge_indices", node_item="node_number")
+    want = []
+    for g in graphs:
+        pk = packer.pack(g).wait()
+        want.append(model([pk["node_number"], pk["node_coordinates"], pk["edge_indices"]]).cpu().numpy())
+        torch.cuda.synchronize()
+        del pk
+    # run ahead: no synchronisation until the end, batches go out of scope immediately
+    packer = BatchPacker(ITEMS, index_item="edge_indices", node_item="node_number")
+    compute = torch.cuda.Stream()
+    outs = []
+    for rounds in range(3):
+        for g in graphs:
+            pk = packer.pack(g)
+            with torch.cuda.stream(compute):
+                pk.wait()
+                outs.append(model([pk["node_number"], pk["node_coordinates"], pk["edge_indices"]]))
+            del pk
+    torch.cuda.synchronize()
+    for k, out in enumerate(outs):
+        assert np.array_equal(out.cpu().numpy(), want[k % len(want)]), "batch %d differs" % k
+
+
 def test_ragged_tensor_from_nested_numpy_reference_example():
     # docstring example of the reference, kgcnn/data/utils.py:138-145
     from gcnn_keras_amd.data import ragged_tensor_from_nested_numpy

@@ -125,3 +125,36 @@ def test_c_oracle_matches_numpy_oracle():
         assert got.shape == ref.shape
         assert np.max(np.abs(got - ref)) <= 1e-5 * np.max(np.abs(ref))
     assert c_oracle.num_threads() >= 1
+
+
+def test_cpu_baseline_ports_agree_with_the_numpy_oracle():
+    """Both legs of bench.py's cpu_baseline (C/OpenMP port, torch-CPU restatement) reproduce the NumPy oracle's SchNet
+    forward: the baseline that is timed is the computation that is checked."""
+    from oracle import c_oracle, torch_oracle
+    b = synth.qm9_like_batch(num_graphs=7, seed=13)
+    p = synth.schnet_params(seed=7, random_bias=True)
+    ref = ko.schnet_forward(p, ko.R(b["node_number"], b["node_splits"]), ko.R(b["node_coordinates"], b["node_splits"]),
+                            ko.R(b["edge_indices"], b["edge_splits"]), depth=3)
+    got_t = torch_oracle.schnet_forward(torch_oracle.to_torch(p), torch_oracle.prepare(b), depth=3)
+    assert got_t.shape == ref.shape
+    assert np.max(np.abs(got_t - ref) / np.maximum(np.abs(ref), 1e-3 * np.max(np.abs(ref)))) <= 1e-5
+    if c_oracle.available():
+        got_c = c_oracle.schnet_forward(p, b["node_number"], b["node_coordinates"], b["edge_indices"], b["node_splits"],
+                                        b["edge_splits"], depth=3)
+        assert np.max(np.abs(got_c - ref) / np.maximum(np.abs(ref), 1e-3 * np.max(np.abs(ref)))) <= 1e-5
+
+
+def test_fused_route_applicability_rules():
+    """Which ``Schnet.make_model`` configurations get the fused route (decided at build time, no GPU needed)."""
+    from gcnn_keras_amd import fused
+    from gcnn_keras_amd.literature import Schnet
+    assert Schnet.make_model().fused is not None and Schnet.make_model(depth=6).fused is not None
+    assert Schnet.make_model(gauss_args={"bins": 25, "distance": 5, "offset": 0.0, "sigma": 0.5}).fused is not None
+    assert Schnet.make_model(interaction_args={"units": 64}).fused is None
+    assert Schnet.make_model(interaction_args={"cfconv_pool": "mean"}).fused is None
+    assert Schnet.make_model(interaction_args={"activation": "relu"}).fused is None
+    assert Schnet.make_model(make_distance=False).fused is None
+    assert Schnet.make_model(output_embedding="node").fused is None
+    assert Schnet.make_model(node_pooling_args={"pooling_method": "mean"}).fused is None
+    assert Schnet.make_model(gauss_args={"bins": 40, "distance": 4, "offset": 0.0, "sigma": 0.4}).fused is None
+    assert not fused.supports({}) and not fused.supports({"interaction_args": {"units": 128}})
