@@ -6,22 +6,7 @@
 
 namespace {
 
-__device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + expf(-x)); }
-
-// d act / d pre
-__device__ __forceinline__ float act_grad(int act, float alpha, float x) {
-  switch (act) {
-    case MP_ACT_RELU: return x > 0.0f ? 1.0f : 0.0f;
-    case MP_ACT_SHIFTED_SOFTPLUS:
-    case MP_ACT_SOFTPLUS2:
-    case MP_ACT_SOFTPLUS: return sigmoidf_(x);
-    case MP_ACT_SWISH: { const float s = sigmoidf_(x); return s + x * s * (1.0f - s); }
-    case MP_ACT_SIGMOID: { const float s = sigmoidf_(x); return s * (1.0f - s); }
-    case MP_ACT_TANH: { const float t = tanhf(x); return 1.0f - t * t; }
-    case MP_ACT_LEAKY_RELU: return x >= 0.0f ? 1.0f : alpha;
-    default: return 1.0f;
-  }
-}
+__device__ __forceinline__ float act_grad(int act, float alpha, float x) { return mp_act_grad(act, alpha, x); }
 
 __global__ void activation_grad_kernel(int act, float alpha, const float* __restrict__ pre,
                                        const float* __restrict__ gy, int64_t n, float* __restrict__ out) {

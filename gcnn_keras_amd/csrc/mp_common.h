@@ -88,3 +88,19 @@ __device__ __forceinline__ float mp_apply_act(int act, float alpha, float v) {
     default: return v;
   }
 }
+
+// d act / d pre-activation (used by the elementwise derivative kernel and by the Dense prologue of the reverse pass)
+__device__ __forceinline__ float mp_sigmoid(float x) { return 1.0f / (1.0f + expf(-x)); }
+__device__ __forceinline__ float mp_act_grad(int act, float alpha, float x) {
+  switch (act) {
+    case MP_ACT_RELU: return x > 0.0f ? 1.0f : 0.0f;
+    case MP_ACT_SHIFTED_SOFTPLUS:
+    case MP_ACT_SOFTPLUS2:
+    case MP_ACT_SOFTPLUS: return mp_sigmoid(x);
+    case MP_ACT_SWISH: { const float s = mp_sigmoid(x); return s + x * s * (1.0f - s); }
+    case MP_ACT_SIGMOID: { const float s = mp_sigmoid(x); return s * (1.0f - s); }
+    case MP_ACT_TANH: { const float t = tanhf(x); return 1.0f - t * t; }
+    case MP_ACT_LEAKY_RELU: return x >= 0.0f ? 1.0f : alpha;
+    default: return 1.0f;
+  }
+}

@@ -17,9 +17,23 @@ using floatx16 = __attribute__((ext_vector_type(16))) float;
 constexpr int BM = 64, BN = 64, BK = 32;
 constexpr int A_LD = BK + 1;
 
+// Prologue / epilogue options of mp_dense_ex_f32 (the fused PaiNN pipeline and its reverse pass): IN_MODE 1 applies an
+// activation to x while the tile is staged (x holds a saved pre-activation: Dense(act) -> Dense becomes one launch per
+// GEMM with only the pre-activation kept), IN_MODE 2 multiplies x by act'(in_pre) (the reverse pass through an
+// activation, fused into the transposed-weight GEMM that follows it); `addend` (nullable, may alias `out`) is added to
+// the result after the output activation (residual adds / gradient accumulation).
+struct DenseExtra {
+  int in_act;
+  float in_alpha;
+  const float* in_pre;   // (R, K) for IN_MODE 2
+  const float* addend;   // (R, U) or null
+};
+
+template <int IN_MODE>
 __global__ __launch_bounds__(256) void dense_mfma_kernel(const float* __restrict__ x, int64_t R, int64_t K,
                                                          const float* __restrict__ W, const float* __restrict__ b,
-                                                         int64_t U, int act, float alpha, float* __restrict__ out) {
+                                                         int64_t U, int act, float alpha, float* __restrict__ out,
+                                                         DenseExtra ex) {
   __shared__ float As[BM * A_LD];
   __shared__ float Bs[BK * BN];
 
@@ -41,7 +55,11 @@ __global__ __launch_bounds__(256) void dense_mfma_kernel(const float* __restrict
       const int idx = tid + i * 256;
       const int ar = idx >> 5, ac = idx & 31;
       const int64_t gr = row0 + ar, gk = k0 + ac;
-      ra[i] = (gr < R && gk < K) ? x[gr * K + gk] : 0.0f;
+      float xv = (gr < R && gk < K) ? x[gr * K + gk] : 0.0f;
+      if constexpr (IN_MODE == 1) xv = (gr < R && gk < K) ? mp_apply_act(ex.in_act, ex.in_alpha, xv) : 0.0f;
+      if constexpr (IN_MODE == 2)
+        xv = (gr < R && gk < K) ? xv * mp_act_grad(ex.in_act, ex.in_alpha, ex.in_pre[gr * K + gk]) : 0.0f;
+      ra[i] = xv;
       const int br = idx >> 6, bc = idx & 63;
       const int64_t gk2 = k0 + br, gc = col0 + bc;
       rb[i] = (gk2 < K && gc < U) ? W[gk2 * U + gc] : 0.0f;
@@ -77,7 +95,11 @@ __global__ __launch_bounds__(256) void dense_mfma_kernel(const float* __restrict
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const int64_t row = row0 + wr * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-      if (row < R) out[row * U + col] = mp_apply_act(act, alpha, acc[r] + bias);
+      if (row < R) {
+        float v = mp_apply_act(act, alpha, acc[r] + bias);
+        if (ex.addend) v += ex.addend[row * U + col];
+        out[row * U + col] = v;
+      }
     }
   }
 }
@@ -162,8 +184,30 @@ int mp_dense_f32(const float* x, int64_t R, int64_t K, const float* W, const flo
   const int64_t gy = mp::ceil_div(R, BM), gx = mp::ceil_div(U, BN);
   MP_REQUIRE(gx <= 65535 && gy < (int64_t{1} << 31), "mp_dense_f32: grid too large");
   dim3 grid(static_cast<unsigned>(gy), static_cast<unsigned>(gx));
-  dense_mfma_kernel<<<grid, 256, 0, mp::as_stream(stream)>>>(x, R, K, W, b, U, act, act_alpha, out);
+  dense_mfma_kernel<0><<<grid, 256, 0, mp::as_stream(stream)>>>(x, R, K, W, b, U, act, act_alpha, out,
+                                                                DenseExtra{0, 0.0f, nullptr, nullptr});
   return mp::check_launch("mp_dense_f32");
+}
+
+int mp_dense_ex_f32(const float* x, int64_t R, int64_t K, const float* W, const float* b, int64_t U, int act,
+                    float act_alpha, int in_mode, int in_act, float in_alpha, const float* in_pre, const float* addend,
+                    float* out, mpStream_t stream) {
+  MP_REQUIRE(R >= 0 && K >= 1 && U >= 1, "mp_dense_ex_f32: bad sizes R=%lld K=%lld U=%lld", (long long)R, (long long)K,
+             (long long)U);
+  MP_REQUIRE(act >= MP_ACT_LINEAR && act <= MP_ACT_SOFTPLUS2 && in_act >= MP_ACT_LINEAR && in_act <= MP_ACT_SOFTPLUS2,
+             "mp_dense_ex_f32: unknown activation");
+  MP_REQUIRE(in_mode >= 0 && in_mode <= 2 && (in_mode != 2 || in_pre != nullptr), "mp_dense_ex_f32: bad prologue mode");
+  if (R == 0) return MP_OK;
+  MP_REQUIRE(x && W && out, "mp_dense_ex_f32: null pointer");
+  const int64_t gy = mp::ceil_div(R, BM), gx = mp::ceil_div(U, BN);
+  MP_REQUIRE(gx <= 65535 && gy < (int64_t{1} << 31), "mp_dense_ex_f32: grid too large");
+  dim3 grid(static_cast<unsigned>(gy), static_cast<unsigned>(gx));
+  const DenseExtra ex{in_act, in_alpha, in_pre, addend};
+  hipStream_t s = mp::as_stream(stream);
+  if (in_mode == 0) dense_mfma_kernel<0><<<grid, 256, 0, s>>>(x, R, K, W, b, U, act, act_alpha, out, ex);
+  else if (in_mode == 1) dense_mfma_kernel<1><<<grid, 256, 0, s>>>(x, R, K, W, b, U, act, act_alpha, out, ex);
+  else dense_mfma_kernel<2><<<grid, 256, 0, s>>>(x, R, K, W, b, U, act, act_alpha, out, ex);
+  return mp::check_launch("mp_dense_ex_f32");
 }
 
 int mp_activation_f32(int act, float act_alpha, const float* x, int64_t n, float* out, mpStream_t stream) {

@@ -47,8 +47,16 @@ struct EdgePrepArgs {
 // matters.  Larger batches search the L2-resident arrays directly (one wave-uniform search + a short walk).
 // `block` / `nblocks`: this workgroup's position among the workgroups doing edge preparation.
 // COL1: also track the sortedness of the sender column (the generic index plan reports both columns).
-template <bool LDS_SPLITS, bool COL1 = false>
-__device__ __forceinline__ void edge_prepare_body(const EdgePrepArgs& p, int64_t block, int64_t nblocks) {
+// Extra: per-edge continuation extra(e, dx, dy, dz, dist) for callers that derive more from the edge vector in the same
+// pass (PaiNN: direction, Bessel basis and its derivative, cosine envelope).
+struct NoEdgeExtra {
+  static constexpr bool active = false;
+  __device__ __forceinline__ void operator()(int64_t, float, float, float, float) const {}
+};
+
+template <bool LDS_SPLITS, bool COL1 = false, class Extra = NoEdgeExtra>
+__device__ __forceinline__ void edge_prepare_body(const EdgePrepArgs& p, int64_t block, int64_t nblocks,
+                                                  const Extra& extra = Extra()) {
   const int64_t* __restrict__ idx = p.idx;
   const int64_t* __restrict__ node_splits = p.node_splits;
   const int64_t* __restrict__ edge_splits = p.edge_splits;
@@ -106,11 +114,13 @@ __device__ __forceinline__ void edge_prepare_body(const EdgePrepArgs& p, int64_t
         if (idx[(e - 1) * 2] + base > si) local_flags |= MP_FLAG_UNSORTED_COL0;
       }
     }
-    if (p.dist) {
+    if (p.dist || Extra::active) {
       const float dx = xyz[si * 3 + 0] - xyz[sj * 3 + 0];
       const float dy = xyz[si * 3 + 1] - xyz[sj * 3 + 1];
       const float dz = xyz[si * 3 + 2] - xyz[sj * 3 + 2];
-      p.dist[e] = sqrtf(fmaxf(dx * dx + dy * dy + dz * dz, 0.0f));
+      const float dist = sqrtf(fmaxf(dx * dx + dy * dy + dz * dz, 0.0f));
+      if (p.dist) p.dist[e] = dist;
+      if constexpr (Extra::active) extra(e, dx, dy, dz, dist);
     }
   }
   mp_publish_flags(p.flags, local_flags);

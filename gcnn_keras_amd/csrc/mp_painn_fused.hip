@@ -1,0 +1,655 @@
+// Fused PaiNN pipeline (kgcnn/literature/PAiNN.py:100-155) and its reverse pass for forces (kgcnn/model/force.py:159-186).
+//
+// The forward of one PaiNN block (kgcnn/layers/conv/painn_conv.py:97-115 PAiNNconv, :201-214 PAiNNUpdate) runs as
+//
+//   GEMM  h1 = z W1 + b1                       GEMM  s = swish(h1) Wphi + bphi          (mp_dense_ex_f32, prologue swish)
+//   EDGE  z' = z + sum_e s_j w_e |1 ,  v' = v + sum_e (s_j w_e)|2 (x) v_j + (s_j w_e)|3 (x) r_ij      (painn_message_kernel)
+//   GEMM  [v_u | v_v] = v' [Wu | Wv]            NODE  c = [z' | ||v_v||],  prod = <v_u, v_v>          (painn_update_pre)
+//   GEMM  h2 = c Wd + bd                        GEMM  a = swish(h2) Wa + ba
+//   NODE  z'' = z' + prod a_sv + a_ss ,  v'' = v' + a_vv (x) v_u                                       (painn_update_post)
+//
+// i.e. five GEMMs on the FP32 matrix cores and three memory-bound kernels per block instead of the ~30 primitive launches
+// of the layer path; none of the (M,3F) / (M,3,F) edge tensors of the reference exists.  The reverse pass mirrors it
+// kernel for kernel (transposed-weight GEMMs with the activation derivative fused as a prologue; the edge kernel runs
+// SENDER-parallel over the CSR of column 1, because the message's inputs s_j, v_j live at the sender: their gradients
+// are then register accumulations of one wave, no atomics, fixed order).  Distances enter through the radial basis and
+// the unit vectors only, so the edge kernel reduces dE/d(rbf_e) to ONE scalar per edge with the basis derivative
+// rbf'(d_e) prepared by stage 0:  dE/dd_e = sum_f g_w[f] (rbf'_e Ww)[f];  a last node-parallel kernel turns
+// (dE/dd_e, dE/dr_ij) into dE/dx over both CSRs.
+//
+// All kernels are HBM/L2-bound streaming or gather kernels except the GEMMs; the per-edge filter (K = B = 20) is far too
+// thin for MFMA tiles and runs on the VALU as packed FP32 FMAs with the lane's weight columns in registers.
+#include "mp_common.h"
+#include "mp_edge_prepare.h"
+
+namespace {
+
+constexpr int F = 128;
+
+__device__ __forceinline__ float ipow(float x, int n) {
+  float r = 1.0f;
+  for (int i = 0; i < n; ++i) r *= x;
+  return r;
+}
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+  return v;
+}
+
+// ---------------------------------------------------------------------------------------------------- stage 0
+// Edge continuation of the index pass: EdgeDirectionNormalized (geom.py:331-378, divide_no_nan), BesselBasisLayer
+// (geom.py:772-785) with the arithmetic of bessel_basis_kernel (csrc/mp_elementwise.hip), its derivative as in
+// bessel_grad_kernel (csrc/mp_backward.hip), CosCutOffEnvelope (geom.py:831-837) and its derivative.
+struct PainnEdgeExtra {
+  static constexpr bool active = true;
+  float* rij;         // (M,3)
+  const float* freq;  // (B)
+  int B;
+  float inv_cutoff;
+  int p;
+  float a, b, c;
+  float* rbf;         // (M,B)
+  float* rbfd;        // (M,B) or null
+  float cos_cutoff;   // <= 0: no envelope
+  float* env;         // (M) or null
+  float* envd;        // (M) or null
+  __device__ __forceinline__ void operator()(int64_t e, float dx, float dy, float dz, float s) const {
+    const float inv = s == 0.0f ? 0.0f : 1.0f / s;
+    rij[e * 3 + 0] = dx * inv;
+    rij[e * 3 + 1] = dy * inv;
+    rij[e * 3 + 2] = dz * inv;
+    const float xs = s * inv_cutoff;
+    const float xp1 = ipow(xs, p - 1);
+    const float envp = 1.0f / xs + a * xp1 + b * (xp1 * xs) + c * (xp1 * xs * xs);
+    const float cut = xs < 1.0f ? envp : 0.0f;
+    const bool inside = xs < 1.0f && xs > 0.0f;
+    float denv = 0.0f, env_in = 0.0f;
+    if (rbfd != nullptr && inside) {
+      const float xp2 = ipow(xs, p - 2);
+      const float xq1 = xp2 * xs;
+      env_in = 1.0f / xs + a * xq1 + b * (xq1 * xs) + c * (xq1 * xs * xs);
+      denv = -1.0f / (xs * xs) + a * (p - 1) * xp2 + b * p * xq1 + c * (p + 1) * (xq1 * xs);
+    }
+    for (int k = 0; k < B; ++k) {
+      const float f = freq[k];
+      rbf[e * B + k] = cut * sinf(f * xs);
+      if (rbfd != nullptr) rbfd[e * B + k] = inside ? (denv * sinf(f * xs) + env_in * f * cosf(f * xs)) * inv_cutoff : 0.0f;
+    }
+    if (env != nullptr) {
+      const float scale = 3.14159265358979323846f / cos_cutoff;
+      const float v = fminf(fmaxf(s, -cos_cutoff), cos_cutoff);
+      env[e] = (cosf(v * scale) + 1.0f) * 0.5f;
+      if (envd != nullptr) envd[e] = (s > -cos_cutoff && s < cos_cutoff) ? -0.5f * scale * sinf(s * scale) : 0.0f;
+    }
+  }
+};
+
+struct PainnNodeInit {
+  const float* numbers;  // (N) float node numbers (Keras Embedding casts to int32)
+  const float* emb;      // (vocab, F)
+  int vocab;
+  int64_t N;
+  float v_init;          // EquivariantInitialize constant (zeros / eps / ones / const)
+  float* z0;             // (N, F)
+  float* v0;             // (N, 3, F)
+};
+
+// Workgroups [0, node_blocks) initialise the node state, the rest run the edge pass.
+template <bool LDS_SPLITS>
+__global__ __launch_bounds__(256) void painn_stage0_kernel(PainnNodeInit ni, mp_prep::EdgePrepArgs p, PainnEdgeExtra ex,
+                                                           int node_blocks) {
+  if (static_cast<int>(blockIdx.x) < node_blocks) {
+    const int64_t total = ni.N * F;
+    for (int64_t t = static_cast<int64_t>(blockIdx.x) * 256 + threadIdx.x; t < total;
+         t += static_cast<int64_t>(node_blocks) * 256) {
+      const int64_t n = t / F;
+      const int f = static_cast<int>(t % F);
+      const int zi = static_cast<int>(ni.numbers[n]);
+      ni.z0[t] = (zi >= 0 && zi < ni.vocab) ? ni.emb[static_cast<int64_t>(zi) * F + f] : 0.0f;
+      ni.v0[(n * 3 + 0) * F + f] = ni.v_init;
+      ni.v0[(n * 3 + 1) * F + f] = ni.v_init;
+      ni.v0[(n * 3 + 2) * F + f] = ni.v_init;
+    }
+  } else {
+    mp_prep::edge_prepare_body<LDS_SPLITS, true, PainnEdgeExtra>(p, static_cast<int64_t>(blockIdx.x) - node_blocks,
+                                                                  static_cast<int64_t>(gridDim.x) - node_blocks, ex);
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------- message, forward
+struct PainnMsgArgs {
+  const float* s;       // (N, 3F)  phi(swish(dense1 z)), node side
+  const float* v;       // (N, 3, F) equivariant features (block input)
+  const float* rbf;     // (M, B)
+  const float* env;     // (M) or null
+  const float* rij;     // (M, 3)
+  const float* Ww;      // (B, 3F)
+  const float* bw;      // (3F) or null
+  const int32_t* ptr;   // (N+1) CSR over receivers
+  const int32_t* perm;  // (M) or null
+  const int32_t* send;  // (M) original edge order
+  const float* z_in;    // (N, F) or null: when given the outputs are the residual sums z_in + ds, v + dv
+  float* ds;            // (N, F)
+  float* dv;            // (N, 3, F)
+  int64_t N, M;
+  int B;
+};
+
+// One wave per receiving node (receiver-parallel over the CSR, sequential in edge order = the order tf.math.segment_sum
+// uses after the stable sort: deterministic).  Lane l holds features 2l, 2l+1 as one register pair, so every gathered row
+// part is ONE 512-B wave read and the filter / product arithmetic is packed FP32 (v_pk_fma_f32).  Edges are taken four at
+// a time: the four senders' rows are all requested before the first is used (the per-edge chain perm -> send -> row is
+// otherwise one dependent L2 round trip per edge).  Wave-uniform data (edge id, sender id, rbf row, r_ij, envelope) is
+// fetched with scalar loads.
+template <int BT>
+__global__ __launch_bounds__(256) void painn_message_kernel(PainnMsgArgs a) {
+  constexpr int MAXB = BT > 0 ? BT : 32;
+  constexpr int EC = 4;
+  const int lane = threadIdx.x & 63;
+  const int B = BT > 0 ? BT : a.B;
+  float2 w[3][MAXB], bias[3];
+#pragma unroll
+  for (int p = 0; p < 3; ++p) {
+#pragma unroll
+    for (int k = 0; k < MAXB; ++k)
+      w[p][k] = k < B ? *reinterpret_cast<const float2*>(a.Ww + k * 3 * F + p * F + 2 * lane) : make_float2(0.f, 0.f);
+    bias[p] = a.bw ? *reinterpret_cast<const float2*>(a.bw + p * F + 2 * lane) : make_float2(0.f, 0.f);
+  }
+  const int64_t nwaves = (static_cast<int64_t>(gridDim.x) * blockDim.x) >> 6;
+  for (int64_t n0 = (static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x) >> 6; n0 < a.N; n0 += nwaves) {
+    const int n = __builtin_amdgcn_readfirstlane(static_cast<int>(n0));
+    int e_lo = a.ptr[n], e_hi = a.ptr[n + 1];
+    e_lo = e_lo < 0 ? 0 : (e_lo > a.M ? static_cast<int>(a.M) : e_lo);
+    e_hi = e_hi < e_lo ? e_lo : (e_hi > a.M ? static_cast<int>(a.M) : e_hi);
+    float2 ds = make_float2(0.f, 0.f), dv[3];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) dv[k] = make_float2(0.f, 0.f);
+    for (int e0 = e_lo; e0 < e_hi; e0 += EC) {
+      int r[EC];
+      float2 sj[EC][3], vj[EC][3];
+#pragma unroll
+      for (int u = 0; u < EC; ++u) {
+        const int e = e0 + u < e_hi ? e0 + u : e_hi - 1;   // the tail repeats the last edge (loads only)
+        r[u] = a.perm ? a.perm[e] : e;
+        int j = a.send[r[u]];
+        j = j < 0 ? 0 : (j >= a.N ? static_cast<int>(a.N) - 1 : j);
+        const float* srow = a.s + static_cast<int64_t>(j) * 3 * F + 2 * lane;
+        const float* vrow = a.v + static_cast<int64_t>(j) * 3 * F + 2 * lane;
+#pragma unroll
+        for (int p = 0; p < 3; ++p) {
+          sj[u][p] = *reinterpret_cast<const float2*>(srow + p * F);
+          vj[u][p] = *reinterpret_cast<const float2*>(vrow + p * F);
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < EC; ++u) {
+        if (e0 + u < e_hi) {   // wave-uniform
+          const float* rb = a.rbf + static_cast<int64_t>(r[u]) * B;
+          float2 f[3];
+#pragma unroll
+          for (int p = 0; p < 3; ++p) f[p] = make_float2(0.f, 0.f);
+#pragma unroll
+          for (int k = 0; k < MAXB; ++k) {
+            if (k < B) {
+              const float x = rb[k];
+#pragma unroll
+              for (int p = 0; p < 3; ++p) {
+                f[p].x = fmaf(x, w[p][k].x, f[p].x);
+                f[p].y = fmaf(x, w[p][k].y, f[p].y);
+              }
+            }
+          }
+          const float envv = a.env ? a.env[r[u]] : 1.0f;
+          float2 sw[3];
+#pragma unroll
+          for (int p = 0; p < 3; ++p) {
+            float wx = f[p].x + bias[p].x, wy = f[p].y + bias[p].y;   // Dense: x W + b
+            if (a.env) { wx *= envv; wy *= envv; }                    // lay_mult_cutoff([w, envelope])
+            sw[p].x = sj[u][p].x * wx;                                // lay_mult([s, w])
+            sw[p].y = sj[u][p].y * wy;
+          }
+          ds.x += sw[0].x;
+          ds.y += sw[0].y;
+#pragma unroll
+          for (int k = 0; k < 3; ++k) {
+            const float rk = a.rij[static_cast<int64_t>(r[u]) * 3 + k];
+            dv[k].x += sw[1].x * vj[u][k].x + sw[2].x * rk;           // (sw2 * v_j) + (sw3 * r_ij)
+            dv[k].y += sw[1].y * vj[u][k].y + sw[2].y * rk;
+          }
+        }
+      }
+    }
+    if (a.z_in) {   // residual adds of PAiNN.py:126-127 fused: z + ds, v + dv
+      const float2 z = *reinterpret_cast<const float2*>(a.z_in + static_cast<int64_t>(n) * F + 2 * lane);
+      ds.x += z.x;
+      ds.y += z.y;
+#pragma unroll
+      for (int k = 0; k < 3; ++k) {
+        const float2 vo = *reinterpret_cast<const float2*>(a.v + (static_cast<int64_t>(n) * 3 + k) * F + 2 * lane);
+        dv[k].x += vo.x;
+        dv[k].y += vo.y;
+      }
+    }
+    *reinterpret_cast<float2*>(a.ds + static_cast<int64_t>(n) * F + 2 * lane) = ds;
+#pragma unroll
+    for (int k = 0; k < 3; ++k)
+      *reinterpret_cast<float2*>(a.dv + (static_cast<int64_t>(n) * 3 + k) * F + 2 * lane) = dv[k];
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------- message, backward
+struct PainnMsgBwdArgs {
+  const float* s;        // (N, 3F)   saved forward s
+  const float* v;        // (N, 3, F) saved block-input v
+  const float* rbf;      // (M, B)
+  const float* rbfd;     // (M, B)   d rbf / d d
+  const float* env;      // (M) or null
+  const float* envd;     // (M) or null
+  const float* rij;      // (M, 3)
+  const float* Ww;       // (B, 3F)
+  const float* bw;       // (3F) or null
+  const int32_t* ptr1;   // (N+1) CSR over SENDERS
+  const int32_t* perm1;  // (M) sender-sorted position -> original edge, or null
+  const int32_t* recv;   // (M) original edge order
+  const float* g_ds;     // (N, F)    upstream gradient of ds (= dE/dz')
+  const float* g_dv;     // (N, 3, F) upstream gradient of dv (= dE/dv')
+  float* g_s;            // (N, 3F)   out
+  float* g_v;            // (N, 3, F) out = g_dv (residual path) + message path; null: not needed (first block)
+  float* g_d;            // (M)    dE/dd_e: written (accumulate = 0) or added to
+  float* g_rij;          // (M, 3) dE/dr_ij
+  int accumulate;
+  int64_t N, M;
+  int B;
+};
+
+// One wave per SENDING node j: s_j and v_j are the wave's own rows, the upstream gradients are gathered from the
+// receivers of j's edges, the gradients w.r.t. s_j and v_j accumulate in registers in edge order (deterministic) and are
+// written once.  Per edge the wave also reduces four scalars (dE/dd_e, dE/dr_ij) over its 128 features; each edge belongs
+// to exactly one sender, so the per-edge accumulators are plain read-modify-writes.
+template <int BT>
+__global__ __launch_bounds__(256) void painn_message_bwd_kernel(PainnMsgBwdArgs a) {
+  constexpr int MAXB = BT > 0 ? BT : 32;
+  const int lane = threadIdx.x & 63;
+  const int B = BT > 0 ? BT : a.B;
+  float2 w[3][MAXB], bias[3];
+#pragma unroll
+  for (int p = 0; p < 3; ++p) {
+#pragma unroll
+    for (int k = 0; k < MAXB; ++k)
+      w[p][k] = k < B ? *reinterpret_cast<const float2*>(a.Ww + k * 3 * F + p * F + 2 * lane) : make_float2(0.f, 0.f);
+    bias[p] = a.bw ? *reinterpret_cast<const float2*>(a.bw + p * F + 2 * lane) : make_float2(0.f, 0.f);
+  }
+  const int64_t nwaves = (static_cast<int64_t>(gridDim.x) * blockDim.x) >> 6;
+  for (int64_t n0 = (static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x) >> 6; n0 < a.N; n0 += nwaves) {
+    const int j = __builtin_amdgcn_readfirstlane(static_cast<int>(n0));
+    int e_lo = a.ptr1[j], e_hi = a.ptr1[j + 1];
+    e_lo = e_lo < 0 ? 0 : (e_lo > a.M ? static_cast<int>(a.M) : e_lo);
+    e_hi = e_hi < e_lo ? e_lo : (e_hi > a.M ? static_cast<int>(a.M) : e_hi);
+    float2 sj[3], vj[3], gs[3], gv[3];
+#pragma unroll
+    for (int p = 0; p < 3; ++p) {
+      sj[p] = *reinterpret_cast<const float2*>(a.s + static_cast<int64_t>(j) * 3 * F + p * F + 2 * lane);
+      vj[p] = *reinterpret_cast<const float2*>(a.v + static_cast<int64_t>(j) * 3 * F + p * F + 2 * lane);
+      gs[p] = make_float2(0.f, 0.f);
+      gv[p] = make_float2(0.f, 0.f);
+    }
+    for (int e = e_lo; e < e_hi; ++e) {
+      const int r = a.perm1 ? a.perm1[e] : e;   // wave-uniform
+      int i = a.recv[r];
+      i = i < 0 ? 0 : (i >= a.N ? static_cast<int>(a.N) - 1 : i);
+      const float2 gz = *reinterpret_cast<const float2*>(a.g_ds + static_cast<int64_t>(i) * F + 2 * lane);
+      float2 gdv[3];
+#pragma unroll
+      for (int k = 0; k < 3; ++k)
+        gdv[k] = *reinterpret_cast<const float2*>(a.g_dv + (static_cast<int64_t>(i) * 3 + k) * F + 2 * lane);
+      const float* rb = a.rbf + static_cast<int64_t>(r) * B;
+      const float* rd = a.rbfd + static_cast<int64_t>(r) * B;
+      float2 f[3], fd[3];
+#pragma unroll
+      for (int p = 0; p < 3; ++p) {
+        f[p] = make_float2(0.f, 0.f);
+        fd[p] = make_float2(0.f, 0.f);
+      }
+#pragma unroll
+      for (int k = 0; k < MAXB; ++k) {
+        if (k < B) {
+          const float x = rb[k], xd = rd[k];
+#pragma unroll
+          for (int p = 0; p < 3; ++p) {
+            f[p].x = fmaf(x, w[p][k].x, f[p].x);
+            f[p].y = fmaf(x, w[p][k].y, f[p].y);
+            fd[p].x = fmaf(xd, w[p][k].x, fd[p].x);
+            fd[p].y = fmaf(xd, w[p][k].y, fd[p].y);
+          }
+        }
+      }
+      float rk[3];
+#pragma unroll
+      for (int k = 0; k < 3; ++k) rk[k] = a.rij[static_cast<int64_t>(r) * 3 + k];
+      // filter and its derivative w.r.t. the distance (the envelope is a second factor: product rule)
+      float2 wf[3], wd[3];
+      const float envv = a.env ? a.env[r] : 1.0f;
+      const float envdv = (a.env && a.envd) ? a.envd[r] : 0.0f;
+#pragma unroll
+      for (int p = 0; p < 3; ++p) {
+        const float wx = f[p].x + bias[p].x, wy = f[p].y + bias[p].y;
+        wf[p].x = a.env ? wx * envv : wx;
+        wf[p].y = a.env ? wy * envv : wy;
+        wd[p].x = a.env ? fd[p].x * envv + wx * envdv : fd[p].x;
+        wd[p].y = a.env ? fd[p].y * envv + wy * envdv : fd[p].y;
+      }
+      // upstream gradients of the three parts of sw = s_j * w
+      float2 gsw[3];
+      gsw[0] = gz;
+      gsw[1].x = gdv[0].x * vj[0].x + gdv[1].x * vj[1].x + gdv[2].x * vj[2].x;
+      gsw[1].y = gdv[0].y * vj[0].y + gdv[1].y * vj[1].y + gdv[2].y * vj[2].y;
+      gsw[2].x = gdv[0].x * rk[0] + gdv[1].x * rk[1] + gdv[2].x * rk[2];
+      gsw[2].y = gdv[0].y * rk[0] + gdv[1].y * rk[1] + gdv[2].y * rk[2];
+      float gd = 0.0f;
+#pragma unroll
+      for (int p = 0; p < 3; ++p) {
+        gs[p].x += gsw[p].x * wf[p].x;
+        gs[p].y += gsw[p].y * wf[p].y;
+        gd += gsw[p].x * sj[p].x * wd[p].x + gsw[p].y * sj[p].y * wd[p].y;
+      }
+      const float2 sw2 = make_float2(sj[1].x * wf[1].x, sj[1].y * wf[1].y);
+      const float2 sw3 = make_float2(sj[2].x * wf[2].x, sj[2].y * wf[2].y);
+      float gr[3];
+#pragma unroll
+      for (int k = 0; k < 3; ++k) {
+        gv[k].x += gdv[k].x * sw2.x;
+        gv[k].y += gdv[k].y * sw2.y;
+        gr[k] = gdv[k].x * sw3.x + gdv[k].y * sw3.y;
+      }
+      gd = wave_sum(gd);
+#pragma unroll
+      for (int k = 0; k < 3; ++k) gr[k] = wave_sum(gr[k]);
+      if (lane == 0) {
+        if (a.accumulate) {
+          a.g_d[r] += gd;
+#pragma unroll
+          for (int k = 0; k < 3; ++k) a.g_rij[static_cast<int64_t>(r) * 3 + k] += gr[k];
+        } else {
+          a.g_d[r] = gd;
+#pragma unroll
+          for (int k = 0; k < 3; ++k) a.g_rij[static_cast<int64_t>(r) * 3 + k] = gr[k];
+        }
+      }
+    }
+#pragma unroll
+    for (int p = 0; p < 3; ++p)
+      *reinterpret_cast<float2*>(a.g_s + static_cast<int64_t>(j) * 3 * F + p * F + 2 * lane) = gs[p];
+    if (a.g_v) {
+#pragma unroll
+      for (int k = 0; k < 3; ++k) {
+        const float2 up = *reinterpret_cast<const float2*>(a.g_dv + (static_cast<int64_t>(j) * 3 + k) * F + 2 * lane);
+        *reinterpret_cast<float2*>(a.g_v + (static_cast<int64_t>(j) * 3 + k) * F + 2 * lane) =
+            make_float2(up.x + gv[k].x, up.y + gv[k].y);
+      }
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------- update, node side
+// uv (3N, 2F): row (n,k) = [v_u | v_v] of component k (one GEMM with the concatenated kernels [Wu | Wv]).
+// pre:  c (N, 2F) = [z' | sqrt(relu(sum_k v_v^2))]  (EuclideanNorm(axis=2), geom.py:181-193; LazyConcatenate),
+//       prod (N, F) = sum_k v_u v_v                   (ScalarProduct(axis=2), geom.py:261)
+__global__ void painn_update_pre_kernel(const float* __restrict__ zp, const float* __restrict__ uv, int64_t N,
+                                        float* __restrict__ c, float* __restrict__ prod) {
+  const int64_t total = N * F;
+  const int64_t stride = static_cast<int64_t>(gridDim.x) * blockDim.x;
+  for (int64_t t = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x; t < total; t += stride) {
+    const int64_t n = t / F;
+    const int f = static_cast<int>(t % F);
+    float pr = 0.0f, sq = 0.0f;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+      const float vu = uv[((n * 3 + k) * 2) * F + f];
+      const float vv = uv[((n * 3 + k) * 2 + 1) * F + f];
+      pr += vu * vv;
+      sq += vv * vv;
+    }
+    c[n * 2 * F + f] = zp[t];
+    c[n * 2 * F + F + f] = sqrtf(fmaxf(sq, 0.0f));
+    prod[t] = pr;
+  }
+}
+
+// post: z'' = z' + prod a_sv + a_ss ; v''[k] = v'[k] + a_vv v_u[k]     (painn_conv.py:208-213 + PAiNN.py:131-132)
+__global__ void painn_update_post_kernel(const float* __restrict__ zp, const float* __restrict__ vp,
+                                         const float* __restrict__ uv, const float* __restrict__ prod,
+                                         const float* __restrict__ a, int64_t N, float* __restrict__ z2,
+                                         float* __restrict__ v2) {
+  const int64_t total = N * F;
+  const int64_t stride = static_cast<int64_t>(gridDim.x) * blockDim.x;
+  for (int64_t t = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x; t < total; t += stride) {
+    const int64_t n = t / F;
+    const int f = static_cast<int>(t % F);
+    const float a_vv = a[n * 3 * F + f], a_sv = a[n * 3 * F + F + f], a_ss = a[n * 3 * F + 2 * F + f];
+    z2[t] = zp[t] + (prod[t] * a_sv + a_ss);
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+      const float vu = uv[((n * 3 + k) * 2) * F + f];
+      v2[(n * 3 + k) * F + f] = vp[(n * 3 + k) * F + f] + a_vv * vu;
+    }
+  }
+}
+
+// reverse of post: g_a (N,3F) = [sum_k g_v2[k] v_u[k] | g_z2 prod | g_z2],  g_prod (N,F) = g_z2 a_sv
+__global__ void painn_update_post_bwd_kernel(const float* __restrict__ gz2, const float* __restrict__ gv2,
+                                             const float* __restrict__ uv, const float* __restrict__ prod,
+                                             const float* __restrict__ a, int64_t N, float* __restrict__ g_a,
+                                             float* __restrict__ g_prod) {
+  const int64_t total = N * F;
+  const int64_t stride = static_cast<int64_t>(gridDim.x) * blockDim.x;
+  for (int64_t t = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x; t < total; t += stride) {
+    const int64_t n = t / F;
+    const int f = static_cast<int>(t % F);
+    float gavv = 0.0f;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) gavv += gv2[(n * 3 + k) * F + f] * uv[((n * 3 + k) * 2) * F + f];
+    const float g = gz2[t];
+    g_a[n * 3 * F + f] = gavv;
+    g_a[n * 3 * F + F + f] = g * prod[t];
+    g_a[n * 3 * F + 2 * F + f] = g;
+    g_prod[t] = g * a[n * 3 * F + F + f];
+  }
+}
+
+// reverse of pre (+ the v_u part of post): with g_c (N,2F) = dE/dc,
+//   g_zp = g_z2 + g_c[:, :F]
+//   g_vu[k] = g_v2[k] a_vv + g_prod v_v[k] ;  g_vv[k] = g_prod v_u[k] + g_c[:, F:] v_v[k] / ||v_v||   (0 at the cusp)
+__global__ void painn_update_pre_bwd_kernel(const float* __restrict__ gz2, const float* __restrict__ gv2,
+                                            const float* __restrict__ uv, const float* __restrict__ c,
+                                            const float* __restrict__ a, const float* __restrict__ g_prod,
+                                            const float* __restrict__ g_c, int64_t N, float* __restrict__ g_zp,
+                                            float* __restrict__ g_uv) {
+  const int64_t total = N * F;
+  const int64_t stride = static_cast<int64_t>(gridDim.x) * blockDim.x;
+  for (int64_t t = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x; t < total; t += stride) {
+    const int64_t n = t / F;
+    const int f = static_cast<int>(t % F);
+    const float nrm = c[n * 2 * F + F + f];
+    const float gn = g_c[n * 2 * F + F + f];
+    const float gp = g_prod[t];
+    const float a_vv = a[n * 3 * F + f];
+    const float inv = nrm > 0.0f ? gn / nrm : 0.0f;   // d sqrt(s) = v_v / sqrt(s); zero sub-gradient at s = 0
+    g_zp[t] = gz2[t] + g_c[n * 2 * F + f];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+      const float vu = uv[((n * 3 + k) * 2) * F + f];
+      const float vv = uv[((n * 3 + k) * 2 + 1) * F + f];
+      g_uv[((n * 3 + k) * 2) * F + f] = gv2[(n * 3 + k) * F + f] * a_vv + gp * vv;
+      g_uv[((n * 3 + k) * 2 + 1) * F + f] = gp * vu + inv * vv;
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------- geometry, backward
+// dE/dx_n = sum_{e: recv = n} t_e - sum_{e: send = n} t_e,  t_e = g_d r_ij + (g_r - (g_r . r_ij) r_ij) / d
+// (d = |x_i - x_j|, r_ij = (x_i - x_j) / d with divide_no_nan: no contribution at d = 0).  One thread per node, both
+// CSRs walked in order: deterministic.  scale = -1 returns the physical force directly.
+__global__ void painn_geometry_bwd_kernel(const float* __restrict__ g_d, const float* __restrict__ g_rij,
+                                          const float* __restrict__ rij, const float* __restrict__ d,
+                                          const int32_t* __restrict__ ptr0, const int32_t* __restrict__ perm0,
+                                          const int32_t* __restrict__ ptr1, const int32_t* __restrict__ perm1, int64_t N,
+                                          int64_t M, float scale, float* __restrict__ gx) {
+  const int64_t stride = static_cast<int64_t>(gridDim.x) * blockDim.x;
+  for (int64_t n = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x; n < N; n += stride) {
+    float acc[3] = {0.0f, 0.0f, 0.0f};
+    for (int side = 0; side < 2; ++side) {
+      const int32_t* ptr = side == 0 ? ptr0 : ptr1;
+      const int32_t* perm = side == 0 ? perm0 : perm1;
+      const float sign = side == 0 ? 1.0f : -1.0f;
+      int lo = ptr[n], hi = ptr[n + 1];
+      lo = lo < 0 ? 0 : lo;
+      hi = hi > M ? static_cast<int>(M) : hi;
+      for (int e = lo; e < hi; ++e) {
+        const int64_t r = perm ? perm[e] : e;
+        const float dist = d[r];
+        if (dist == 0.0f) continue;
+        const float r0 = rij[r * 3], r1 = rij[r * 3 + 1], r2 = rij[r * 3 + 2];
+        const float q0 = g_rij[r * 3], q1 = g_rij[r * 3 + 1], q2 = g_rij[r * 3 + 2];
+        const float dot = q0 * r0 + q1 * r1 + q2 * r2;
+        const float inv = 1.0f / dist;
+        const float gd = g_d[r];
+        acc[0] += sign * (gd * r0 + (q0 - dot * r0) * inv);
+        acc[1] += sign * (gd * r1 + (q1 - dot * r1) * inv);
+        acc[2] += sign * (gd * r2 + (q2 - dot * r2) * inv);
+      }
+    }
+    gx[n * 3 + 0] = scale * acc[0];
+    gx[n * 3 + 1] = scale * acc[1];
+    gx[n * 3 + 2] = scale * acc[2];
+  }
+}
+
+}  // namespace
+
+extern "C" {
+
+int mp_painn_stage0_f32(const float* numbers, int64_t N, const float* emb, int vocab, float v_init, float* z0, float* v0,
+                        const int64_t* idx, int64_t M, const int64_t* node_splits, const int64_t* edge_splits, int64_t G,
+                        const float* xyz, const float* frequencies, int num_radial, float bessel_cutoff,
+                        int envelope_exponent, float cos_cutoff, int32_t* recv, int32_t* send, int32_t* flags, float* dist,
+                        float* rij, float* rbf, float* rbfd, float* env, float* envd, mpStream_t stream) {
+  MP_REQUIRE(N >= 0 && M >= 0 && G >= 0 && vocab >= 1, "mp_painn_stage0_f32: bad sizes");
+  MP_REQUIRE(num_radial >= 1 && num_radial <= 32 && bessel_cutoff != 0.0f && envelope_exponent >= 1,
+             "mp_painn_stage0_f32: bad Bessel basis arguments");
+  MP_REQUIRE(N < (int64_t{1} << 31) && M < (int64_t{1} << 31), "mp_painn_stage0_f32: N, M must fit int32");
+  if (N == 0) return MP_OK;
+  MP_REQUIRE(numbers && emb && z0 && v0 && node_splits && edge_splits && flags, "mp_painn_stage0_f32: null pointer");
+  MP_REQUIRE(M == 0 || (idx && xyz && frequencies && recv && send && dist && rij && rbf),
+             "mp_painn_stage0_f32: null edge pointer");
+  MP_REQUIRE(cos_cutoff <= 0.0f || env != nullptr, "mp_painn_stage0_f32: envelope requested without a buffer");
+  PainnNodeInit ni{numbers, emb, vocab, N, v_init, z0, v0};
+  mp_prep::EdgePrepArgs p{idx, M, node_splits, edge_splits, G, N, xyz, recv, send, dist, flags};
+  const int pe = envelope_exponent + 1;
+  PainnEdgeExtra ex{};
+  ex.rij = rij; ex.freq = frequencies; ex.B = num_radial; ex.inv_cutoff = 1.0f / bessel_cutoff; ex.p = pe;
+  ex.a = static_cast<float>(-(pe + 1) * (pe + 2) / 2.0);
+  ex.b = static_cast<float>(pe * (pe + 2));
+  ex.c = static_cast<float>(-pe * (pe + 1) / 2.0);
+  ex.rbf = rbf; ex.rbfd = rbfd; ex.cos_cutoff = cos_cutoff;
+  ex.env = cos_cutoff > 0.0f ? env : nullptr;
+  ex.envd = cos_cutoff > 0.0f ? envd : nullptr;
+  const int node_blocks = static_cast<int>(mp::grid_for(N * F));
+  const int edge_blocks = M > 0 ? static_cast<int>(mp::grid_for(M)) : 0;
+  hipStream_t s = mp::as_stream(stream);
+  if (G <= mp_prep::PREP_LDS_GRAPHS)
+    painn_stage0_kernel<true><<<node_blocks + edge_blocks, 256, 0, s>>>(ni, p, ex, node_blocks);
+  else
+    painn_stage0_kernel<false><<<node_blocks + edge_blocks, 256, 0, s>>>(ni, p, ex, node_blocks);
+  return mp::check_launch("mp_painn_stage0_f32");
+}
+
+int mp_painn_message_f32(const float* s, const float* v, int64_t N, const float* rbf, int B, const float* env,
+                         const float* rij, const float* Ww, const float* bw, const int32_t* ptr, const int32_t* perm,
+                         const int32_t* send, int64_t M, const float* z_in, float* ds, float* dv, mpStream_t stream) {
+  MP_REQUIRE(N >= 0 && M >= 0 && B >= 1 && B <= 32, "mp_painn_message_f32: bad sizes (B must be 1..32)");
+  if (N == 0) return MP_OK;
+  MP_REQUIRE(s && v && Ww && ptr && ds && dv && (M == 0 || (rbf && rij && send)), "mp_painn_message_f32: null pointer");
+  MP_REQUIRE(M < (int64_t{1} << 31) && N < (int64_t{1} << 31), "mp_painn_message_f32: sizes must fit int32");
+  MP_REQUIRE(dv != v, "mp_painn_message_f32: dv must not alias v (other waves still gather v)");
+  PainnMsgArgs a{s, v, rbf, env, rij, Ww, bw, ptr, perm, send, z_in, ds, dv, N, M, B};
+  int64_t blocks = mp::ceil_div(N, 4);
+  if (blocks > 2048) blocks = 2048;
+  hipStream_t st = mp::as_stream(stream);
+  if (B == 20) painn_message_kernel<20><<<static_cast<unsigned>(blocks), 256, 0, st>>>(a);
+  else painn_message_kernel<0><<<static_cast<unsigned>(blocks), 256, 0, st>>>(a);
+  return mp::check_launch("mp_painn_message_f32");
+}
+
+int mp_painn_message_bwd_f32(const float* s, const float* v, int64_t N, const float* rbf, const float* rbfd, int B,
+                             const float* env, const float* envd, const float* rij, const float* Ww, const float* bw,
+                             const int32_t* ptr1, const int32_t* perm1, const int32_t* recv, int64_t M, const float* g_ds,
+                             const float* g_dv, float* g_s, float* g_v, float* g_d, float* g_rij, int accumulate,
+                             mpStream_t stream) {
+  MP_REQUIRE(N >= 0 && M >= 0 && B >= 1 && B <= 32, "mp_painn_message_bwd_f32: bad sizes (B must be 1..32)");
+  if (N == 0) return MP_OK;
+  MP_REQUIRE(s && v && Ww && ptr1 && g_ds && g_dv && g_s && (M == 0 || (rbf && rbfd && rij && recv && g_d && g_rij)),
+             "mp_painn_message_bwd_f32: null pointer");
+  MP_REQUIRE(M < (int64_t{1} << 31) && N < (int64_t{1} << 31), "mp_painn_message_bwd_f32: sizes must fit int32");
+  MP_REQUIRE(g_v != g_dv, "mp_painn_message_bwd_f32: g_v must not alias g_dv (other waves still gather g_dv)");
+  PainnMsgBwdArgs a{s, v, rbf, rbfd, env, envd, rij, Ww, bw, ptr1, perm1, recv, g_ds, g_dv, g_s, g_v, g_d, g_rij,
+                    accumulate, N, M, B};
+  int64_t blocks = mp::ceil_div(N, 4);
+  if (blocks > 2048) blocks = 2048;
+  hipStream_t st = mp::as_stream(stream);
+  if (B == 20) painn_message_bwd_kernel<20><<<static_cast<unsigned>(blocks), 256, 0, st>>>(a);
+  else painn_message_bwd_kernel<0><<<static_cast<unsigned>(blocks), 256, 0, st>>>(a);
+  return mp::check_launch("mp_painn_message_bwd_f32");
+}
+
+int mp_painn_update_pre_f32(const float* zp, const float* uv, int64_t N, float* c, float* prod, mpStream_t stream) {
+  MP_REQUIRE(N >= 0, "mp_painn_update_pre_f32: bad size");
+  if (N == 0) return MP_OK;
+  MP_REQUIRE(zp && uv && c && prod, "mp_painn_update_pre_f32: null pointer");
+  painn_update_pre_kernel<<<mp::grid_for(N * F), 256, 0, mp::as_stream(stream)>>>(zp, uv, N, c, prod);
+  return mp::check_launch("mp_painn_update_pre_f32");
+}
+
+int mp_painn_update_post_f32(const float* zp, const float* vp, const float* uv, const float* prod, const float* a,
+                             int64_t N, float* z2, float* v2, mpStream_t stream) {
+  MP_REQUIRE(N >= 0, "mp_painn_update_post_f32: bad size");
+  if (N == 0) return MP_OK;
+  MP_REQUIRE(zp && vp && uv && prod && a && z2 && v2, "mp_painn_update_post_f32: null pointer");
+  painn_update_post_kernel<<<mp::grid_for(N * F), 256, 0, mp::as_stream(stream)>>>(zp, vp, uv, prod, a, N, z2, v2);
+  return mp::check_launch("mp_painn_update_post_f32");
+}
+
+int mp_painn_update_post_bwd_f32(const float* g_z2, const float* g_v2, const float* uv, const float* prod,
+                                 const float* a, int64_t N, float* g_a, float* g_prod, mpStream_t stream) {
+  MP_REQUIRE(N >= 0, "mp_painn_update_post_bwd_f32: bad size");
+  if (N == 0) return MP_OK;
+  MP_REQUIRE(g_z2 && g_v2 && uv && prod && a && g_a && g_prod, "mp_painn_update_post_bwd_f32: null pointer");
+  painn_update_post_bwd_kernel<<<mp::grid_for(N * F), 256, 0, mp::as_stream(stream)>>>(g_z2, g_v2, uv, prod, a, N, g_a,
+                                                                                       g_prod);
+  return mp::check_launch("mp_painn_update_post_bwd_f32");
+}
+
+int mp_painn_update_pre_bwd_f32(const float* g_z2, const float* g_v2, const float* uv, const float* c, const float* a,
+                                const float* g_prod, const float* g_c, int64_t N, float* g_zp, float* g_uv,
+                                mpStream_t stream) {
+  MP_REQUIRE(N >= 0, "mp_painn_update_pre_bwd_f32: bad size");
+  if (N == 0) return MP_OK;
+  MP_REQUIRE(g_z2 && g_v2 && uv && c && a && g_prod && g_c && g_zp && g_uv, "mp_painn_update_pre_bwd_f32: null pointer");
+  painn_update_pre_bwd_kernel<<<mp::grid_for(N * F), 256, 0, mp::as_stream(stream)>>>(g_z2, g_v2, uv, c, a, g_prod, g_c,
+                                                                                      N, g_zp, g_uv);
+  return mp::check_launch("mp_painn_update_pre_bwd_f32");
+}
+
+int mp_edge_geometry_bwd_f32(const float* g_d, const float* g_rij, const float* rij, const float* dist,
+                             const int32_t* ptr0, const int32_t* perm0, const int32_t* ptr1, const int32_t* perm1,
+                             int64_t N, int64_t M, float scale, float* g_xyz, mpStream_t stream) {
+  MP_REQUIRE(N >= 0 && M >= 0, "mp_edge_geometry_bwd_f32: bad sizes");
+  if (N == 0) return MP_OK;
+  MP_REQUIRE(ptr0 && ptr1 && g_xyz && (M == 0 || (g_d && g_rij && rij && dist)), "mp_edge_geometry_bwd_f32: null pointer");
+  painn_geometry_bwd_kernel<<<mp::grid_for(N, 64), 64, 0, mp::as_stream(stream)>>>(g_d, g_rij, rij, dist, ptr0, perm0,
+                                                                                   ptr1, perm1, N, M, scale, g_xyz);
+  return mp::check_launch("mp_edge_geometry_bwd_f32");
+}
+
+}  // extern "C"

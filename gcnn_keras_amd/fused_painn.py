@@ -1,0 +1,378 @@
+"""Fused PaiNN forward and energy + force pass (kgcnn/literature/PAiNN.py:100-155 inside kgcnn/model/force.py:159-201).
+
+Per block five FP32-MFMA GEMMs (``mp_dense_ex_f32``: activations and their derivatives ride in the GEMM prologue,
+residual adds in its epilogue) and three memory-bound kernels (csrc/mp_painn_fused.hip): ~28 launches for a depth-3
+forward and ~26 more for the reverse pass that yields dE/dx, all replayed from ONE HIP graph per bound batch.  The reverse
+pass is written out kernel by kernel here - no tape: every saved tensor is a buffer of the batch slot.
+
+    stage0    Embedding, EquivariantInitialize, index pass, r_ij, d, Bessel basis (+ d rbf / d d when forces are wanted)
+    block i   h1 = z W1 + b1 | s = act(h1) Wphi + bphi | message kernel (z' = z + ds, v' = v + dv)
+              uv = v' [Wu|Wv] | c = [z'|norm], prod | h2 = c Wd + bd | a = act(h2) Wa + ba | z'' , v''
+    readout   PoolingNodes(sum) -> output MLP
+    reverse   readout^T | per block, last to first: post^T, Wa^T, Wd^T (x act'), pre^T, [Wu|Wv]^T, message^T
+              (sender-parallel; per-edge dE/dd, dE/dr_ij), Wphi^T, W1^T (x act') | geometry^T -> forces
+"""
+import ctypes
+
+import numpy as np
+import torch
+
+from . import _ffi
+
+_SUM = ("sum", "segment_sum", "reduce_sum")
+_CONST_INIT = {"zeros": 0.0, "eps": 1e-7, "ones": 1.0}
+
+
+def _as_list(v, n):
+    return list(v) if isinstance(v, (list, tuple)) else [v] * n
+
+
+def supports(config):
+    """True if a ``PAiNN.make_model`` configuration (merged keyword dictionary) maps onto the fused pipeline."""
+    try:
+        inputs, conv, upd, om = config["inputs"], config["conv_args"], config["update_args"], config["output_mlp"]
+        if len(inputs) != 3 or len(inputs[0]["shape"]) != 1 or tuple(inputs[1]["shape"])[-1] != 3:
+            return False
+        units = _as_list(om["units"], 1)
+        acts = _as_list(om.get("activation"), len(units))
+        init = config["equiv_initialize_kwargs"]
+        for a in [conv.get("activation", "swish"), upd.get("activation", "swish")] + acts:
+            _ffi.activation_code(a)
+        return bool(
+            conv.get("units") == 128 and upd.get("units") == 128 and conv.get("conv_pool", "sum") in _SUM
+            and conv.get("use_bias", True) is True and upd.get("use_bias", True) is True
+            and config["input_embedding"]["node"]["output_dim"] == 128
+            and not config.get("equiv_normalization") and not config.get("node_normalization")
+            and config.get("output_embedding", "graph") == "graph"
+            and config["pooling_args"].get("pooling_method") in _SUM
+            and int(init.get("dim", 3)) == 3 and (init.get("method", "zeros") in _CONST_INIT or init.get("method") == "const")
+            and 1 <= int(config["bessel_basis"]["num_radial"]) <= 32
+            and int(config["bessel_basis"]["envelope_exponent"]) >= 1
+            and acts[-1] in ("linear", None) and all(_as_list(om.get("use_bias", True), len(units)))
+            and int(config["depth"]) >= 1)
+    except (KeyError, TypeError, IndexError, ValueError):
+        return False
+
+
+def make_images(p, depth, n_out, out=None):
+    """Weight layouts the reverse pass and the fused update need, made once per weight update: ``[Wu | Wv]`` side by side
+    (one GEMM yields v_u and v_v) and the transposed kernels.  ``out`` re-fills existing images in place."""
+    def put(name, value):
+        if out is not None:
+            out[name].copy_(value)
+        else:
+            images[name] = value.contiguous().clone()
+
+    images = {} if out is None else out
+    for i in range(depth):
+        c, u = "conv%d/" % i, "update%d/" % i
+        uv = torch.cat([p[u + "lin_u/kernel"], p[u + "lin_v/kernel"]], dim=1)
+        put("uv%d" % i, uv)
+        put("uvT%d" % i, uv.t())
+        for name in (c + "dense1", c + "phi", u + "dense1", u + "a"):
+            put(name + "/T", p[name + "/kernel"].t())
+    for k in range(n_out):
+        put("output_mlp/%d/T" % k, p["output_mlp/%d/kernel" % k].t())
+    return images
+
+
+class FusedPainn:
+    """One batch slot: buffers, the two captured graphs (energy only; energy + forces) of ONE bound batch."""
+
+    def __init__(self, p, images, cfg):
+        if not torch.cuda.is_available():
+            raise _ffi.EngineError("FusedPainn needs an MI355X (no CPU fallback)")
+        self.p, self.w, self.cfg = p, images, cfg
+        self.depth = int(cfg["depth"])
+        self.B = int(cfg["bessel_basis"]["num_radial"])
+        self.act_conv = _ffi.activation_code(cfg["conv_args"].get("activation", "swish"))
+        self.act_upd = _ffi.activation_code(cfg["update_args"].get("activation", "swish"))
+        units = _as_list(cfg["output_mlp"]["units"], 1)
+        self.out_units = [int(u) for u in units]
+        self.act_out = [_ffi.activation_code(a) for a in _as_list(cfg["output_mlp"].get("activation"), len(units))]
+        init = cfg["equiv_initialize_kwargs"]
+        self.v_init = float(init.get("value", 1.0)) if init.get("method") == "const" else _CONST_INIT[init.get("method", "zeros")]
+        cutoff = cfg["conv_args"].get("cutoff")
+        self.cos_cutoff = float(cutoff) if cutoff is not None else -1.0
+        self.stream = torch.cuda.Stream()
+        self.graphs = {}
+        self.calls = 0
+
+    # ------------------------------------------------------------------------------------------------ binding
+    def bind(self, node, xyz, idx, grad):
+        """Attach resident ragged inputs; allocates every buffer of the forward (and of the reverse pass if ``grad``)."""
+        self.inputs = (node, xyz, idx)
+        self.grad = bool(grad)
+        n, m, g = int(node.values.shape[0]), int(idx.values.shape[0]), node.nrows()
+        self.N, self.M, self.G = n, m, g
+        dev, f32 = node.values.device, torch.float32
+        e = lambda *shape: torch.empty(shape, dtype=f32, device=dev)
+        plan = idx.index_plan(node)          # CSRs of both columns (receiver: forward; sender: reverse pass)
+        if plan.flags_host() & _ffi.MP_FLAG_OOB:
+            raise IndexError("edge index out of range for its graph")
+        self.ptr0, self.perm0, _ = plan.csr(0)
+        self.ptr1, self.perm1, _ = plan.csr(1) if self.grad else (None, None, None)
+        mm = max(m, 1)
+        self.recv = torch.empty(mm, dtype=torch.int32, device=dev)
+        self.send = torch.empty(mm, dtype=torch.int32, device=dev)
+        self.flags = torch.zeros(1, dtype=torch.int32, device=dev)
+        self.dist, self.rij, self.rbf = e(mm), e(mm, 3), e(mm, self.B)
+        self.rbfd = e(mm, self.B) if self.grad else None
+        self.env = e(mm) if self.cos_cutoff > 0 else None
+        self.envd = e(mm) if (self.cos_cutoff > 0 and self.grad) else None
+        self.z0, self.v0 = e(n, 128), e(n, 3, 128)
+        nblk = self.depth if self.grad else 1   # the reverse pass needs every block's intermediates
+        self.blk = [{"h1": e(n, 128), "s": e(n, 384), "zp": e(n, 128), "vp": e(n, 3, 128), "uv": e(3 * n, 256),
+                     "c": e(n, 256), "prod": e(n, 128), "h2": e(n, 128), "a": e(n, 384)} for _ in range(nblk)]
+        nzv = self.depth if self.grad else 2    # block outputs: all of them (v_in of the next block is saved) or ping-pong
+        self.zs = [e(n, 128) for _ in range(nzv)]
+        self.vs = [e(n, 3, 128) for _ in range(nzv)]
+        self.pooled = e(g, 128)
+        self.pre_out = [e(g, u) for u in self.out_units]
+        splits = node.row_splits_host()
+        rows = g
+        while rows > 0 and splits[rows] == splits[rows - 1]:
+            rows -= 1
+        self.out_rows = rows   # tf.math.segment_sum drops trailing empty graphs (kgcnn/layers/pooling.py:215-219)
+        if self.grad:
+            if self.out_units[-1] != 1:
+                raise ValueError("fused forces are built for one energy state")
+            self.ones = torch.ones((g, 1), dtype=f32, device=dev)
+            self.g_out = [e(g, u) for u in ([128] + self.out_units[:-1])]   # dE/d(input of output layer k)
+            self.gz, self.gv = e(n, 128), e(n, 3, 128)
+            self.g_a, self.g_prod, self.g_a2, self.g_c = e(n, 384), e(n, 128), e(n, 128), e(n, 256)
+            self.g_zp, self.g_uv, self.g_vp = e(n, 128), e(3 * n, 256), e(n, 3, 128)
+            self.g_s, self.g_a1 = e(n, 384), e(n, 128)
+            self.g_d, self.g_rij = e(mm), e(mm, 3)
+            self.force = e(n, 3)
+        self.graphs = {}
+
+    # ------------------------------------------------------------------------------------------------ launches
+    @staticmethod
+    def _dense(x, rows, k, w, b, u, out, in_mode=0, in_act=0, in_pre=None, addend=None):
+        _ffi.call("mp_dense_ex_f32", _ffi.ptr(x), rows, k, _ffi.ptr(w), _ffi.ptr(b), u, 0, 0.0, in_mode, in_act, 0.0,
+                  _ffi.ptr(in_pre), _ffi.ptr(addend), _ffi.ptr(out), _ffi.stream())
+
+    def _forward(self):
+        p, w, n, m = self.p, self.w, self.N, self.M
+        node, xyz, idx = self.inputs
+        _ffi.call("mp_painn_stage0_f32", _ffi.ptr(node.values), n, _ffi.ptr(p["embedding"]),
+                  int(p["embedding"].shape[0]), self.v_init, _ffi.ptr(self.z0), _ffi.ptr(self.v0), _ffi.ptr(idx.values), m,
+                  _ffi.ptr(node.row_splits), _ffi.ptr(idx.row_splits), self.G, _ffi.ptr(xyz.values),
+                  _ffi.ptr(p["bessel/frequencies"]), self.B, float(self.cfg["bessel_basis"]["cutoff"]),
+                  int(self.cfg["bessel_basis"]["envelope_exponent"]), self.cos_cutoff, _ffi.ptr(self.recv),
+                  _ffi.ptr(self.send), _ffi.ptr(self.flags), _ffi.ptr(self.dist), _ffi.ptr(self.rij), _ffi.ptr(self.rbf),
+                  _ffi.ptr(self.rbfd), _ffi.ptr(self.env), _ffi.ptr(self.envd), _ffi.stream())
+        z, v = self.z0, self.v0
+        for i in range(self.depth):
+            c, u = "conv%d/" % i, "update%d/" % i
+            t = self.blk[i if self.grad else 0]
+            z_out, v_out = self.zs[i % len(self.zs)], self.vs[i % len(self.vs)]
+            self._dense(z, n, 128, p[c + "dense1/kernel"], p.get(c + "dense1/bias"), 128, t["h1"])
+            self._dense(t["h1"], n, 128, p[c + "phi/kernel"], p.get(c + "phi/bias"), 384, t["s"], in_mode=1,
+                        in_act=self.act_conv)
+            _ffi.call("mp_painn_message_f32", _ffi.ptr(t["s"]), _ffi.ptr(v), n, _ffi.ptr(self.rbf), self.B,
+                      _ffi.ptr(self.env), _ffi.ptr(self.rij), _ffi.ptr(p[c + "w/kernel"]), _ffi.ptr(p.get(c + "w/bias")),
+                      _ffi.ptr(self.ptr0), _ffi.ptr(self.perm0), _ffi.ptr(self.send), m, _ffi.ptr(z), _ffi.ptr(t["zp"]),
+                      _ffi.ptr(t["vp"]), _ffi.stream())
+            self._dense(t["vp"], 3 * n, 128, w["uv%d" % i], None, 256, t["uv"])
+            _ffi.call("mp_painn_update_pre_f32", _ffi.ptr(t["zp"]), _ffi.ptr(t["uv"]), n, _ffi.ptr(t["c"]),
+                      _ffi.ptr(t["prod"]), _ffi.stream())
+            self._dense(t["c"], n, 256, p[u + "dense1/kernel"], p.get(u + "dense1/bias"), 128, t["h2"])
+            self._dense(t["h2"], n, 128, p[u + "a/kernel"], p.get(u + "a/bias"), 384, t["a"], in_mode=1,
+                        in_act=self.act_upd)
+            _ffi.call("mp_painn_update_post_f32", _ffi.ptr(t["zp"]), _ffi.ptr(t["vp"]), _ffi.ptr(t["uv"]),
+                      _ffi.ptr(t["prod"]), _ffi.ptr(t["a"]), n, _ffi.ptr(z_out), _ffi.ptr(v_out), _ffi.stream())
+            z, v = z_out, v_out
+        # PoolingNodes(sum) + output MLP (PAiNN.py:146-147); every layer keeps its pre-activation
+        _ffi.call("mp_pool_graph_f32", _ffi.MP_SUM, _ffi.ptr(z), _ffi.ptr(node.row_splits), self.G, 128, None,
+                  _ffi.ptr(self.pooled), _ffi.stream())
+        x, k_in = self.pooled, 128
+        for k, units in enumerate(self.out_units):
+            self._dense(x, self.G, k_in, p["output_mlp/%d/kernel" % k], p.get("output_mlp/%d/bias" % k), units,
+                        self.pre_out[k], in_mode=1 if k > 0 else 0, in_act=self.act_out[k - 1] if k > 0 else 0)
+            x, k_in = self.pre_out[k], units
+
+    def _backward(self):
+        """dE/dx for one energy state: the forward's kernels mirrored, last to first (kgcnn/model/force.py:159-177 computes
+        the same derivative with a GradientTape)."""
+        p, w, n, m = self.p, self.w, self.N, self.M
+        node = self.inputs[0]
+        last = len(self.out_units) - 1
+        t, k_in = self.ones, self.out_units[-1]
+        for k in range(last, -1, -1):   # t = dE/d act_k(pre_k) -> dE/d(input of layer k)
+            width = 128 if k == 0 else self.out_units[k - 1]
+            self._dense(t, self.G, k_in, w["output_mlp/%d/T" % k], None, width, self.g_out[k],
+                        in_mode=2 if k < last else 0, in_act=self.act_out[k], in_pre=self.pre_out[k] if k < last else None)
+            t, k_in = self.g_out[k], width
+        _ffi.call("mp_repeat_rows_f32", _ffi.ptr(t), _ffi.ptr(node.row_splits), self.G, 128, n, _ffi.ptr(self.gz),
+                  _ffi.stream())
+        self.gv.zero_()                 # the readout sees z only
+        for i in range(self.depth - 1, -1, -1):
+            c, u = "conv%d/" % i, "update%d/" % i
+            b = self.blk[i]
+            v_in = self.v0 if i == 0 else self.vs[i - 1]
+            _ffi.call("mp_painn_update_post_bwd_f32", _ffi.ptr(self.gz), _ffi.ptr(self.gv), _ffi.ptr(b["uv"]),
+                      _ffi.ptr(b["prod"]), _ffi.ptr(b["a"]), n, _ffi.ptr(self.g_a), _ffi.ptr(self.g_prod), _ffi.stream())
+            self._dense(self.g_a, n, 384, w[u + "a/T"], None, 128, self.g_a2)
+            self._dense(self.g_a2, n, 128, w[u + "dense1/T"], None, 256, self.g_c, in_mode=2, in_act=self.act_upd,
+                        in_pre=b["h2"])
+            _ffi.call("mp_painn_update_pre_bwd_f32", _ffi.ptr(self.gz), _ffi.ptr(self.gv), _ffi.ptr(b["uv"]),
+                      _ffi.ptr(b["c"]), _ffi.ptr(b["a"]), _ffi.ptr(self.g_prod), _ffi.ptr(self.g_c), n,
+                      _ffi.ptr(self.g_zp), _ffi.ptr(self.g_uv), _ffi.stream())
+            self._dense(self.g_uv, 3 * n, 256, w["uvT%d" % i], None, 128, self.g_vp, addend=self.gv)
+            _ffi.call("mp_painn_message_bwd_f32", _ffi.ptr(b["s"]), _ffi.ptr(v_in), n, _ffi.ptr(self.rbf),
+                      _ffi.ptr(self.rbfd), self.B, _ffi.ptr(self.env), _ffi.ptr(self.envd), _ffi.ptr(self.rij),
+                      _ffi.ptr(p[c + "w/kernel"]), _ffi.ptr(p.get(c + "w/bias")), _ffi.ptr(self.ptr1),
+                      _ffi.ptr(self.perm1), _ffi.ptr(self.recv), m, _ffi.ptr(self.g_zp), _ffi.ptr(self.g_vp),
+                      _ffi.ptr(self.g_s), _ffi.ptr(self.gv) if i > 0 else None, _ffi.ptr(self.g_d), _ffi.ptr(self.g_rij),
+                      0 if i == self.depth - 1 else 1, _ffi.stream())
+            if i > 0:   # block 0's inputs (embedding, constant v) do not depend on the coordinates
+                self._dense(self.g_s, n, 384, w[c + "phi/T"], None, 128, self.g_a1)
+                self._dense(self.g_a1, n, 128, w[c + "dense1/T"], None, 128, self.gz, in_mode=2, in_act=self.act_conv,
+                            in_pre=b["h1"], addend=self.g_zp)
+        _ffi.call("mp_edge_geometry_bwd_f32", _ffi.ptr(self.g_d), _ffi.ptr(self.g_rij), _ffi.ptr(self.rij),
+                  _ffi.ptr(self.dist), _ffi.ptr(self.ptr0), _ffi.ptr(self.perm0), _ffi.ptr(self.ptr1),
+                  _ffi.ptr(self.perm1), n, m, -1.0, _ffi.ptr(self.force), _ffi.stream())
+
+    def _launch(self, with_forces):
+        self._forward()
+        if with_forces:
+            self._backward()
+
+    # ------------------------------------------------------------------------------------------------ execution
+    def run_current(self, with_forces, how="graph"):
+        """One pass of the bound batch on torch's current stream.  Returns ``(energy (G', L), force (N, 3) | None)`` -
+        this slot's static buffers; ``force`` is the physical force -dE/dx."""
+        if with_forces and not self.grad:
+            raise _ffi.EngineError("this batch was bound without the reverse-pass buffers")
+        if how == "graph":
+            graph = self.graphs.get(bool(with_forces))
+            if graph is None:
+                torch.cuda.current_stream().synchronize()
+                with torch.cuda.stream(self.stream):
+                    self._launch(with_forces)   # warm-up outside capture
+                    self.stream.synchronize()
+                    _ffi.call("mp_graph_begin", _ffi.stream())
+                    try:
+                        self._launch(with_forces)
+                    finally:
+                        exe = ctypes.c_void_p()
+                        _ffi.call("mp_graph_end", _ffi.stream(), ctypes.byref(exe))
+                graph = self.graphs[bool(with_forces)] = exe
+            _ffi.call("mp_graph_launch", graph, _ffi.stream())
+        else:
+            self._launch(with_forces)
+        eng = self.pre_out[-1]
+        return (eng if self.out_rows == self.G else eng[:self.out_rows]), (self.force if with_forces else None)
+
+    def check_flags(self):
+        f = int(self.flags.item())
+        if f & _ffi.MP_FLAG_OOB:
+            raise IndexError("edge index out of range for its graph")
+
+    def __del__(self):
+        try:
+            for g in self.graphs.values():
+                _ffi.call("mp_graph_destroy", g)
+        except Exception:
+            pass
+
+
+class PainnFusedRoute:
+    """The fused pipeline behind ``PAiNN.make_model(...)(inputs)`` and behind ``EnergyForceModel`` wrapping such a model.
+
+    Same contract as ``fused.SchnetFusedRoute``: the kernels read the model's live weight tensors (derived layouts are
+    refreshed when a weight's version counter moves), every distinct input set owns a batch slot, the first call issues
+    the launches eagerly, later calls replay the slot's captured HIP graph, everything runs on torch's current stream,
+    results are returned as fresh tensors."""
+
+    def __init__(self, tensors, cfg, max_slots=8):
+        self._tensors, self.cfg = tensors, cfg
+        self.depth = int(cfg["depth"])
+        self.n_out = len(_as_list(cfg["output_mlp"]["units"], 1))
+        self.single_state = int(_as_list(cfg["output_mlp"]["units"], 1)[-1]) == 1
+        self.max_slots = int(max_slots)
+        self.mode = "auto"       # auto: eager launches on first sight of a batch, graph replay afterwards | graph | eager
+        self.copy_output = True
+        self._slots, self._p, self._wkey, self._images = {}, None, None, None
+        self.last = None
+
+    @staticmethod
+    def accepts(inputs, with_forces=False):
+        from .autograd import needs_grad
+        from .ragged import RaggedTensor
+        if not (isinstance(inputs, (list, tuple)) and len(inputs) == 3
+                and all(isinstance(x, RaggedTensor) for x in inputs)):
+            return False
+        z, xyz, idx = (x.values for x in inputs)
+        return (z.is_cuda and z.dtype == torch.float32 and z.dim() == 1 and xyz.dtype == torch.float32
+                and xyz.dim() == 2 and int(xyz.shape[1]) == 3 and idx.dtype == torch.int64 and idx.dim() == 2
+                and int(idx.shape[1]) == 2 and z.is_contiguous() and xyz.is_contiguous() and idx.is_contiguous()
+                and int(xyz.shape[0]) == int(z.shape[0]) and inputs[0].nrows() == inputs[2].nrows()
+                and (with_forces or not needs_grad(z, xyz)))
+
+    def _sync_weights(self):
+        p = self._tensors()
+        key = tuple((id(t), t._version) for t in p.values() if t is not None)
+        if key == self._wkey:
+            return
+        moved = self._wkey is None or tuple(k[0] for k in key) != tuple(k[0] for k in self._wkey)
+        torch.cuda.synchronize()
+        if moved:
+            self._slots.clear()
+            self._p = {k: v for k, v in p.items() if v is not None}
+            self._images = make_images(self._p, self.depth, self.n_out)
+        else:
+            make_images(self._p, self.depth, self.n_out, out=self._images)
+        self._wkey = key
+
+    @staticmethod
+    def _key(node, xyz, idx, grad):
+        return (node.values.data_ptr(), xyz.values.data_ptr(), idx.values.data_ptr(), node.row_splits.data_ptr(),
+                idx.row_splits.data_ptr(), int(node.values.shape[0]), int(idx.values.shape[0]), node.nrows(),
+                idx.values._version, idx.row_splits._version, node.row_splits._version, bool(grad))
+
+    def _slot(self, inputs, grad):
+        node, xyz, idx = inputs
+        self._sync_weights()
+        key = self._key(node, xyz, idx, grad)
+        slot = self._slots.get(key)
+        if slot is None:
+            slot = FusedPainn(self._p, self._images, self.cfg)
+            slot.bind(node, xyz, idx, grad)
+            while len(self._slots) >= self.max_slots:
+                self._slots.pop(next(iter(self._slots)))
+            self._slots[key] = slot
+        elif next(reversed(self._slots)) != key:
+            self._slots[key] = self._slots.pop(key)
+        slot.calls += 1
+        how = self.mode
+        if how == "auto":
+            how = "eager" if slot.calls == 1 else "graph"
+        self.last = how
+        return slot, how
+
+    def __call__(self, inputs):
+        slot, how = self._slot(inputs, grad=False)
+        eng, _ = slot.run_current(False, how)
+        return eng.clone() if self.copy_output else eng
+
+    def energy_force(self, inputs):
+        """``(energy (G', 1), force (N, 3))`` with force = -dE/dx (physical sign)."""
+        if not self.single_state:
+            raise ValueError("fused forces are built for one energy state")
+        slot, how = self._slot(inputs, grad=True)
+        eng, force = slot.run_current(True, how)
+        return (eng.clone(), force.clone()) if self.copy_output else (eng, force)
+
+    def slot_of(self, inputs, grad=False):
+        return self._slots.get(self._key(*inputs, grad))
+
+    def check_flags(self):
+        for slot in self._slots.values():
+            slot.check_flags()
+
+    def release(self):
+        torch.cuda.synchronize()
+        self._slots.clear()

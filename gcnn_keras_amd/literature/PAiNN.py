@@ -7,6 +7,7 @@ from ..layers.geom import (BesselBasisLayer, CosCutOffEnvelope, EdgeDirectionNor
 from ..layers.mlp import MLP, GraphMLP
 from ..layers.modules import LazyAdd, OptionalInputEmbedding
 from ..layers.pooling import PoolingNodes
+from .. import fused_painn as _fused
 from ..model.utils import Model, update_model_kwargs
 
 __model_version__ = "2022.11.25"
@@ -57,7 +58,14 @@ def make_model(inputs: list = None, input_embedding: dict = None, equiv_initiali
     cast = ChangeTensorType(input_tensor_type="ragged", output_tensor_type="tensor") \
         if (output_embedding == "node" and output_to_tensor) else None
 
-    def forward(model_inputs, **kwargs):
+    def forward(model_inputs, fused=None, **kwargs):
+        # Fused pipeline (gcnn_keras_amd/fused_painn.py: per block five MFMA GEMMs + three fused kernels, one HIP graph per
+        # bound batch) whenever configuration and inputs fit it and no gradient is requested; ``fused=False`` forces the
+        # layer sequence below.  Forces take the fused reverse pass through ``EnergyForceModel`` (model/force.py).
+        if route is not None and fused is not False and route.accepts(model_inputs):
+            return route(model_inputs)
+        if fused is True:
+            raise ValueError("this PAiNN configuration / these inputs do not fit the fused pipeline")
         node_input, xyz_input, edi = model_inputs[:3]
         z = embed(node_input)
         v = model_inputs[3] if len(model_inputs) > 3 else equiv_init(z)
@@ -90,6 +98,29 @@ def make_model(inputs: list = None, input_embedding: dict = None, equiv_initiali
     for i in range(depth):
         layers += [convs[i], updates[i]]
     layers.append(out_mlp)
+
+    def fused_tensors():
+        """The model's live weight tensors under the names of ``synth.painn_params``."""
+        p = {"embedding": embed.embeddings, "bessel/frequencies": lay_rbf.frequencies}
+        for i in range(depth):
+            c, u = "conv%d/" % i, "update%d/" % i
+            for name, lay in (("dense1", convs[i].lay_dense1), ("phi", convs[i].lay_phi), ("w", convs[i].lay_w)):
+                p[c + name + "/kernel"], p[c + name + "/bias"] = lay.kernel, lay.bias
+            p[u + "dense1/kernel"], p[u + "dense1/bias"] = updates[i].lay_dense1.kernel, updates[i].lay_dense1.bias
+            p[u + "lin_u/kernel"], p[u + "lin_v/kernel"] = updates[i].lay_lin_u.kernel, updates[i].lay_lin_v.kernel
+            p[u + "a/kernel"], p[u + "a/bias"] = updates[i].lay_a.kernel, updates[i].lay_a.bias
+        for k, d in enumerate(out_mlp.mlp_dense_layer_list):
+            p["output_mlp/%d/kernel" % k], p["output_mlp/%d/bias" % k] = d.kernel, d.bias
+        return p
+
+    merged = {"inputs": inputs, "input_embedding": input_embedding, "equiv_initialize_kwargs": equiv_initialize_kwargs,
+              "bessel_basis": bessel_basis, "depth": depth, "pooling_args": pooling_args, "conv_args": conv_args,
+              "update_args": update_args, "equiv_normalization": equiv_normalization,
+              "node_normalization": node_normalization, "output_embedding": output_embedding, "output_mlp": output_mlp}
+    route = None
+    if _fused.supports(merged) and embed.use_embedding:
+        route = _fused.PainnFusedRoute(fused_tensors, merged)
     model = Model(name, forward, layers, config={"depth": depth, "conv_args": conv_args, "update_args": update_args})
     model.__kgcnn_model_version__ = __model_version__
+    model.fused = route   # None: this configuration always runs the layer path
     return model

@@ -150,6 +150,15 @@ int mp_scatter_relational_f32(int op, const float* edges, int64_t M, int64_t row
 int mp_dense_f32(const float* x, int64_t R, int64_t K, const float* W, const float* b, int64_t U, int act,
                  float act_alpha, float* out, mpStream_t stream);
 
+/* Dense with a fused prologue / epilogue, for chains of Dense layers and their reverse pass (PAiNNconv / PAiNNUpdate,
+ * kgcnn/layers/conv/painn_conv.py:98-99, 206-207; EnergyForceModel's tape, kgcnn/model/force.py:159-177):
+ * in_mode 0: as mp_dense_f32; 1: x := in_act(x) while staging (x is a saved pre-activation); 2: x := x * in_act'(in_pre)
+ * (in_pre (R,K): the reverse pass through an activation, fused into the GEMM with the transposed kernel).
+ * addend (R,U) nullable, may alias out: out = act(x W + b) + addend. */
+int mp_dense_ex_f32(const float* x, int64_t R, int64_t K, const float* W, const float* b, int64_t U, int act,
+                    float act_alpha, int in_mode, int in_act, float in_alpha, const float* in_pre, const float* addend,
+                    float* out, mpStream_t stream);
+
 int mp_activation_f32(int act, float act_alpha, const float* x, int64_t n, float* out, mpStream_t stream);
 int mp_softmax_rows_f32(const float* x, int64_t R, int64_t C, float* out, mpStream_t stream);
 /* GraphLayerNormalization over the last axis of the values (kgcnn/layers/norm.py:8-110 = Keras LayerNormalization):
@@ -250,6 +259,51 @@ int mp_painn_message_fused_f32(const float* s, const float* v, int64_t N, const 
                                const float* rij, const float* Ww, const float* bw, const int32_t* ptr,
                                const int32_t* perm, const int32_t* send, int64_t M, float* ds, float* dv,
                                mpStream_t stream);
+
+/* ---------------------------------------------------------------- fused PaiNN path (+ reverse pass) ------ */
+/* Stage 0 of kgcnn/literature/PAiNN.py:100-119 in one launch: OptionalInputEmbedding (z0 (N,128)), EquivariantInitialize
+ * with a constant (v0 (N,3,128) = v_init), mp_index_prepare_i64 for K = 2 (recv, send, flag word incl. both sortedness
+ * bits), NodePosition -> EdgeDirectionNormalized (rij (M,3), geom.py:331-378) -> NodeDistanceEuclidean (dist (M)) ->
+ * BesselBasisLayer (rbf (M,B), geom.py:772-785) and, if rbfd != NULL, d rbf / d dist (M,B) for the reverse pass;
+ * cos_cutoff > 0 adds CosCutOffEnvelope (env (M), geom.py:831-837) and its derivative envd (nullable). */
+int mp_painn_stage0_f32(const float* numbers, int64_t N, const float* emb, int vocab, float v_init, float* z0, float* v0,
+                        const int64_t* idx, int64_t M, const int64_t* node_splits, const int64_t* edge_splits, int64_t G,
+                        const float* xyz, const float* frequencies, int num_radial, float bessel_cutoff,
+                        int envelope_exponent, float cos_cutoff, int32_t* recv, int32_t* send, int32_t* flags, float* dist,
+                        float* rij, float* rbf, float* rbfd, float* env, float* envd, mpStream_t stream);
+/* mp_painn_message_fused_f32 with the residual adds of PAiNN.py:126-127 fused (z_in != NULL: ds := z_in + ds,
+ * dv := v + dv; dv must not alias v), four edges in flight per wave, packed FP32 arithmetic. */
+int mp_painn_message_f32(const float* s, const float* v, int64_t N, const float* rbf, int B, const float* env,
+                         const float* rij, const float* Ww, const float* bw, const int32_t* ptr, const int32_t* perm,
+                         const int32_t* send, int64_t M, const float* z_in, float* ds, float* dv, mpStream_t stream);
+/* Reverse pass of the message block (painn_conv.py:99-113) for forces: sender-parallel over the CSR of column 1
+ * (ptr1 / perm1).  Given g_ds (N,F) and g_dv (N,3,F): g_s (N,3F) = dE/ds, g_v (N,3,F) = g_dv + dE/dv through the
+ * messages (nullable), and per edge dE/dd (through the filter: rbfd = d rbf / d d, envelope by the product rule) and
+ * dE/dr_ij, written (accumulate = 0) or added (accumulate = 1, later blocks) to g_d (M), g_rij (M,3). */
+int mp_painn_message_bwd_f32(const float* s, const float* v, int64_t N, const float* rbf, const float* rbfd, int B,
+                             const float* env, const float* envd, const float* rij, const float* Ww, const float* bw,
+                             const int32_t* ptr1, const int32_t* perm1, const int32_t* recv, int64_t M, const float* g_ds,
+                             const float* g_dv, float* g_s, float* g_v, float* g_d, float* g_rij, int accumulate,
+                             mpStream_t stream);
+/* PAiNNUpdate.call (painn_conv.py:201-214) around its GEMMs; uv (3N,2F) = v [Wu | Wv] (rows (n,k)):
+ * pre:  c (N,2F) = [z | EuclideanNorm_k(v_v)], prod (N,F) = ScalarProduct_k(v_u, v_v);
+ * post: z2 = z + prod a_sv + a_ss, v2 = v + a_vv (x) v_u  with a (N,3F) = [a_vv | a_sv | a_ss] (+ PAiNN.py:131-132);
+ * post_bwd: g_a (N,3F), g_prod (N,F) from g_z2, g_v2;  pre_bwd: g_z = g_z2 + g_c[:, :F], g_uv (3N,2F). */
+int mp_painn_update_pre_f32(const float* z, const float* uv, int64_t N, float* c, float* prod, mpStream_t stream);
+int mp_painn_update_post_f32(const float* z, const float* v, const float* uv, const float* prod, const float* a,
+                             int64_t N, float* z2, float* v2, mpStream_t stream);
+int mp_painn_update_post_bwd_f32(const float* g_z2, const float* g_v2, const float* uv, const float* prod,
+                                 const float* a, int64_t N, float* g_a, float* g_prod, mpStream_t stream);
+int mp_painn_update_pre_bwd_f32(const float* g_z2, const float* g_v2, const float* uv, const float* c, const float* a,
+                                const float* g_prod, const float* g_c, int64_t N, float* g_z, float* g_uv,
+                                mpStream_t stream);
+/* Reverse of NodePosition -> EdgeDirectionNormalized / NodeDistanceEuclidean (PAiNN.py:116-118; Schnet.py:116-117 with
+ * g_rij = 0): g_xyz[n] = scale * (sum_{recv(e)=n} t_e - sum_{send(e)=n} t_e), t_e = g_d r_ij + (g_rij - (g_rij.r_ij) r_ij)/d,
+ * over the receiver CSR (ptr0/perm0) and the sender CSR (ptr1/perm1); scale = -1 yields the physical force
+ * (kgcnn/model/force.py:188-189). */
+int mp_edge_geometry_bwd_f32(const float* g_d, const float* g_rij, const float* rij, const float* dist,
+                             const int32_t* ptr0, const int32_t* perm0, const int32_t* ptr1, const int32_t* perm1,
+                             int64_t N, int64_t M, float scale, float* g_xyz, mpStream_t stream);
 
 /* Node-side chains of kgcnn/literature/Schnet.py:110-133 / schnet_conv.py:159-165 (F = 128, embedding width 64):
  * node_in:     n = Embedding(Z) W0 + b0 ; x = n Wx

@@ -26,6 +26,10 @@ def num_threads():
     return int(lib().mpo_num_threads())
 
 
+def set_num_threads(n):
+    lib().mpo_set_num_threads(ctypes.c_int(int(n)))
+
+
 def schnet_forward(params, z, xyz, idx, node_splits, edge_splits, depth=3, gauss_args=None):
     """Same contract as ``kgcnn_oracle.schnet_forward`` (graph output ``(G, 1)``), weights in constructor order."""
     ga = gauss_args or {"bins": 20, "distance": 4, "offset": 0.0, "sigma": 0.4}

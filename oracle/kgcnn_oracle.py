@@ -661,7 +661,8 @@ def schnet_forward(params, node_number, xyz, idx, depth=3, gauss_args=None, act=
     (graph output, ``make_distance=True, expand_distance=True``)."""
     gauss_args = gauss_args or {"bins": 20, "distance": 4, "offset": 0.0, "sigma": 0.4}
     inter = {}
-    n = embedding(node_number, params["embedding"])
+    # OptionalInputEmbedding (kgcnn/layers/modules.py:526-534): 2-D node attributes pass through unchanged
+    n = embedding(node_number, params["embedding"]) if "embedding" in params else node_number
     pos1, pos2 = node_position(xyz, idx)
     ed = node_distance_euclidean(pos1, pos2)
     inter["distance"] = ed.values

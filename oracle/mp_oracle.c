@@ -30,6 +30,15 @@ int mpo_num_threads(void) {
 #endif
 }
 
+/* bench.py picks the thread count that is fastest on the host (a 128-graph batch does not scale to 128 threads) */
+void mpo_set_num_threads(int n) {
+#ifdef _OPENMP
+  if (n >= 1) omp_set_num_threads(n);
+#else
+  (void)n;
+#endif
+}
+
 /* tf.nn.softplus thresholds (see kgcnn_oracle.softplus) minus log(2): kgcnn/ops/activ.py:15 */
 static inline float ssp(float x) {
   const float thr = -13.942385f;

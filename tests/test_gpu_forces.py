@@ -97,3 +97,95 @@ def test_energy_force_model_config_and_errors():
                                        "config": {"depth": 1}}, energy_output=0)
     cfg = m.get_config()
     assert cfg["coordinate_input"] == 1 and cfg["output_as_dict"] is True and cfg["model_energy"]["config"]["depth"] == 1
+
+
+def test_schnet_energy_force_at_64_graphs():
+    """Energy + forces at BASELINE batch size through the tape (SchNet has no fused reverse pass): energy rows against the
+    oracle, per-molecule force sums ~ 0, and finite differences of the float64 oracle for two of the 64 molecules."""
+    from gcnn_keras_amd import sharding
+    from gcnn_keras_amd.literature import Schnet
+    from gcnn_keras_amd.model.force import EnergyForceModel
+    from helpers import fd_gradient, mol_inputs
+    from parity import assert_rows_close
+    b = synth.qm9_like_batch(num_graphs=64, seed=2345)
+    p = synth.schnet_params(seed=7, random_bias=True)
+    energy = Schnet.make_model(depth=3)
+    energy.set_weights(list(p.values()))
+    model = EnergyForceModel(model_energy=energy, coordinate_input=1, energy_output=0, output_to_tensor=False,
+                             output_squeeze_states=True)
+    out = model(mol_inputs(b))
+    eng, force = out["energy"].cpu().numpy(), out["force"].values.cpu().numpy()
+    ref = ko.schnet_forward(p, ko.R(b["node_number"], b["node_splits"]), ko.R(b["node_coordinates"], b["node_splits"]),
+                            ko.R(b["edge_indices"], b["edge_splits"]), depth=3)
+    assert_rows_close(eng, ref, what="SchNet energy at 64 graphs")
+    scale = float(np.max(np.abs(force)))
+    ns = b["node_splits"]
+    sums = np.stack([force[ns[g]:ns[g + 1]].sum(0) for g in range(64)])
+    assert np.max(np.abs(sums)) <= 2e-5 * scale
+    p64 = ko.to_dtype(p, np.float64)
+    for g in (3, 40):
+        sub = sharding.take_shard(b, g, g + 1)
+        fn = lambda x: ko.schnet_forward(p64, ko.R(sub["node_number"], sub["node_splits"]), ko.R(x, sub["node_splits"]),
+                                         ko.R(sub["edge_indices"], sub["edge_splits"]), depth=3)
+        ref_f = -fd_gradient(fn, sub["node_coordinates"])
+        got = force[ns[g]:ns[g + 1]]
+        assert np.max(np.abs(got - ref_f)) <= 2e-4 * max(float(np.max(np.abs(ref_f))), 1e-3 * scale), g
+
+
+def test_energy_force_model_esp_branch():
+    """QM/MM branch (kgcnn/model/force.py:153-158, 165-168, 179-186): the energy model consumes the electrostatic
+    potential at the atoms, esp (batch,[N]); the force gains dE/desp * desp/dr.  The energy model here is SchNet on 2-D
+    node attributes [features | esp]; reference forces are float64 finite differences of the oracle energy w.r.t. both the
+    coordinates and esp, combined by the reference's formula."""
+    from gcnn_keras_amd.layers.modules import concat_last
+    from gcnn_keras_amd.literature import Schnet
+    from gcnn_keras_amd.model.force import EnergyForceModel
+    from helpers import dev, fd_gradient
+    b = synth.qm9_like_batch(num_graphs=2, seed=19)
+    n = int(b["node_splits"][-1])
+    rng = np.random.default_rng(5)
+    feat = rng.normal(size=(n, 4)).astype(np.float32)
+    esp = rng.normal(scale=0.3, size=(n,)).astype(np.float32)
+    desp_dr = rng.normal(scale=0.2, size=(n, 3)).astype(np.float32)
+    p = synth.schnet_params(seed=7, random_bias=True, emb_out=5)
+    del p["embedding"]                                    # 2-D node attributes: no embedding layer
+    schnet = Schnet.make_model(depth=2, inputs=[{"shape": (None, 5), "name": "node_attributes", "dtype": "float32",
+                                                 "ragged": True},
+                                                {"shape": (None, 3), "name": "node_coordinates", "dtype": "float32",
+                                                 "ragged": True},
+                                                {"shape": (None, 2), "name": "edge_indices", "dtype": "int64",
+                                                 "ragged": True}])
+    keep = [k for k in p if not k.startswith("interaction2/")]
+    schnet.set_weights([p[k] for k in keep])
+    assert schnet.fused is None                            # attributes instead of numbers: layer path
+
+    def energy_model(inputs, **kwargs):
+        f, xyz, idx, e, _ = inputs
+        attr = f.with_values(concat_last([f.values, e.values.unsqueeze(-1)]))
+        return schnet([attr, xyz, idx])
+
+    model = EnergyForceModel(model_energy=energy_model, coordinate_input=1, esp_input=3, esp_grad_input=4,
+                             energy_output=0, output_to_tensor=False, output_squeeze_states=True)
+    assert model.get_config()["esp_input"] == 3 and model.get_config()["esp_grad_input"] == 4
+    inputs = [dev(feat, b["node_splits"]), dev(b["node_coordinates"], b["node_splits"]),
+              dev(b["edge_indices"], b["edge_splits"]), dev(esp, b["node_splits"]), dev(desp_dr, b["node_splits"])]
+    out = model(inputs)
+    eng, force = out["energy"].cpu().numpy(), out["force"].values.cpu().numpy()
+    p64 = ko.to_dtype({k: p[k] for k in keep}, np.float64)
+
+    def oracle_energy(xyz, e):
+        attr = np.concatenate([feat.astype(np.float64), np.asarray(e, np.float64)[:, None]], axis=1)
+        return ko.schnet_forward(p64, ko.R(attr, b["node_splits"]), ko.R(xyz, b["node_splits"]),
+                                 ko.R(b["edge_indices"], b["edge_splits"]), depth=2)
+
+    ref_e = oracle_energy(b["node_coordinates"].astype(np.float64), esp)
+    assert np.max(np.abs(eng - ref_e)) <= 1e-5 * np.max(np.abs(ref_e))
+    de_dx = fd_gradient(lambda x: oracle_energy(x, esp), b["node_coordinates"])
+    de_desp = fd_gradient(lambda e: oracle_energy(b["node_coordinates"].astype(np.float64), e), esp)
+    ref_f = -(de_dx + de_desp[:, None] * desp_dr.astype(np.float64))
+    assert np.max(np.abs(de_desp[:, None] * desp_dr)) > 0.05 * np.max(np.abs(ref_f))   # the chain term matters here
+    assert np.max(np.abs(force - ref_f)) <= 2e-4 * np.max(np.abs(ref_f)), np.max(np.abs(force - ref_f))
+    # with only one of the two inputs named the branch is not taken (force.py:153): plain -dE/dx
+    plain = EnergyForceModel(model_energy=energy_model, coordinate_input=1, esp_input=3, energy_output=0,
+                             output_to_tensor=False, output_squeeze_states=True)(inputs)
+    assert np.max(np.abs(plain["force"].values.cpu().numpy() + de_dx)) <= 2e-4 * np.max(np.abs(de_dx))

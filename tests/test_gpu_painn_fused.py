@@ -1,0 +1,143 @@
+"""Fused PaiNN pipeline (gcnn_keras_amd/fused_painn.py, csrc/mp_painn_fused.hip) behind ``PAiNN.make_model`` and behind
+``EnergyForceModel``: BASELINE config 3 (64 MD17-shaped graphs, energy + forces) against the CPU oracle, against the
+layer path, and through size-independent properties (forces of a molecule sum to zero; graphs are independent).
+
+Forces: the oracle has no autograd, so its reference forces are central finite differences of its float64 energy -
+taken per molecule (graphs are independent), which keeps the cost linear in the batch."""
+import numpy as np
+import pytest
+import torch
+
+from gcnn_keras_amd import sharding, synth
+from helpers import fd_gradient, mol_inputs, painn_weight_list
+from oracle import kgcnn_oracle as ko
+from parity import assert_rows_close, rowwise_rel
+
+pytestmark = pytest.mark.gpu
+
+
+def _model(p, **kw):
+    from gcnn_keras_amd.literature import PAiNN
+    kw.setdefault("equiv_initialize_kwargs", {"dim": 3, "method": "eps"})
+    model = PAiNN.make_model(**kw)
+    model.set_weights(painn_weight_list(p, depth=kw.get("depth", 3)))
+    return model
+
+
+def _oracle(p, b, dtype=np.float32, cutoff=None, depth=3, xyz=None):
+    pp = ko.to_dtype(p, dtype)
+    xyz = b["node_coordinates"] if xyz is None else xyz
+    return ko.painn_forward(pp, ko.R(b["node_number"], b["node_splits"]), ko.R(xyz.astype(dtype), b["node_splits"]),
+                            ko.R(b["edge_indices"], b["edge_splits"]), depth=depth, equiv_method="eps", cutoff=cutoff)
+
+
+def _oracle_forces_of_graph(p, b, g, cutoff=None):
+    sub = sharding.take_shard(b, g, g + 1)
+    grad = fd_gradient(lambda x: _oracle(p, sub, np.float64, cutoff=cutoff, xyz=x), sub["node_coordinates"])
+    return -grad
+
+
+@pytest.mark.parametrize("num_graphs,seed", [(2, 5), (64, 2345)])
+def test_painn_make_model_fused_forward(num_graphs, seed):
+    from gcnn_keras_amd import _ffi
+    b = synth.md17_like_batch(num_graphs=num_graphs, seed=seed)
+    p = synth.painn_params(seed=8, random_bias=True)
+    model = _model(p)
+    assert model.fused is not None
+    x = mol_inputs(b)
+    before = _ffi.launch_count()
+    out1 = model(x)
+    assert model.fused.last == "eager" and _ffi.launch_count() - before <= 1 + 8 * 3 + 3 + 4   # + index plan at bind
+    out2 = model(x)
+    assert model.fused.last == "graph" and torch.equal(out1, out2)
+    got = out1.cpu().numpy()
+    assert got.shape == (num_graphs, 1)
+    assert_rows_close(got, _oracle(p, b), _oracle(p, b, np.float64), what="fused PaiNN forward")
+    layers = model(x, fused=False).cpu().numpy()
+    assert rowwise_rel(layers, got) <= 1e-5
+    model.fused.check_flags()
+
+
+def test_painn_energy_force_config3_fused():
+    """BASELINE config 3: 64 aspirin-shaped molecules, energy (64,1) and forces (64,21,3) from ONE captured graph."""
+    from gcnn_keras_amd.model.force import EnergyForceModel
+    b = synth.md17_like_batch(num_graphs=64, seed=2345)
+    assert int(b["node_splits"][-1]) == 1344 and int(b["edge_splits"][-1]) == 20586      # BASELINE.md calibration
+    p = synth.painn_params(seed=8, random_bias=True)
+    energy = _model(p)
+    model = EnergyForceModel(model_energy=energy, coordinate_input=1, energy_output=0, output_as_dict=True,
+                             output_to_tensor=True, output_squeeze_states=True)
+    x = mol_inputs(b)
+    out = model(x)
+    assert energy.fused.last == "eager"
+    out2 = model(x)
+    assert energy.fused.last == "graph"
+    eng, force = out["energy"].cpu().numpy(), out["force"].cpu().numpy()
+    assert eng.shape == (64, 1) and force.shape == (64, 21, 3)
+    assert np.array_equal(eng, out2["energy"].cpu().numpy()) and np.array_equal(force, out2["force"].cpu().numpy())
+    assert_rows_close(eng, _oracle(p, b), _oracle(p, b, np.float64), what="fused PaiNN energy")
+    scale = float(np.max(np.abs(force)))
+    # size-independent property: the forces of every molecule sum to zero (translation invariance of the energy)
+    assert np.max(np.abs(force.sum(axis=1))) <= 2e-5 * scale
+    # the tape + layer-by-layer reverse pass gives the same forces (two float32 pipelines)
+    model.fused = False
+    ref_layers = model(x)
+    assert np.max(np.abs(ref_layers["force"].cpu().numpy() - force)) <= 2e-5 * scale
+    assert rowwise_rel(ref_layers["energy"].cpu().numpy(), eng) <= 1e-5
+    # finite differences of the float64 oracle energy, molecule by molecule (three of the 64)
+    for g in (0, 17, 63):
+        ref = _oracle_forces_of_graph(p, b, g)
+        assert np.max(np.abs(force[g] - ref)) <= 1e-4 * max(float(np.max(np.abs(ref))), 1e-3 * scale), g
+
+
+def test_painn_fused_cutoff_envelope_unsorted_edges_and_weight_update():
+    """conv cutoff (cosine envelope on the filter, incl. its derivative in the reverse pass), receivers shuffled inside
+    the graphs (stable-sort route), trailing graph without edges, and a weight update after the batch was captured."""
+    from gcnn_keras_amd.model.force import EnergyForceModel
+    b = synth.md17_like_batch(num_graphs=3, seed=77)
+    rng = np.random.default_rng(3)
+    idx = b["edge_indices"].copy()
+    for g in range(3):
+        lo, hi = b["edge_splits"][g], b["edge_splits"][g + 1]
+        idx[lo:hi] = idx[lo:hi][rng.permutation(hi - lo)]
+    b["edge_indices"] = idx
+    # a fourth molecule with two atoms further apart than the 5 A edge cutoff: no edges
+    b["node_number"] = np.concatenate([b["node_number"], np.array([6., 8.], np.float32)])
+    b["node_coordinates"] = np.concatenate([b["node_coordinates"], np.array([[0, 0, 0], [9, 0, 0]], np.float32)])
+    b["node_splits"] = np.concatenate([b["node_splits"], [b["node_splits"][-1] + 2]])
+    b["edge_splits"] = np.concatenate([b["edge_splits"], [b["edge_splits"][-1]]])
+    conv = {"units": 128, "cutoff": 5.0, "conv_pool": "sum"}
+    for seed in (8, 9):
+        p = synth.painn_params(seed=seed, random_bias=True)
+        if seed == 8:
+            energy = _model(p, conv_args=conv)
+            model = EnergyForceModel(model_energy=energy, coordinate_input=1, energy_output=0, output_to_tensor=False,
+                                     output_squeeze_states=True)
+            x = mol_inputs(b)
+            model(x), model(x)                       # bound and captured with the first weights
+        else:
+            energy.set_weights(painn_weight_list(p))  # same tensors, new values: derived layouts are refreshed
+        out = model(x)
+        eng, force = out["energy"].cpu().numpy(), out["force"].values.cpu().numpy()
+        assert eng.shape == (4, 1) and force.shape == (65, 3)
+        assert_rows_close(eng, _oracle(p, b, cutoff=5.0), _oracle(p, b, np.float64, cutoff=5.0), what="cutoff energy")
+        scale = float(np.max(np.abs(force)))
+        for g in (0, 2, 3):
+            ref = _oracle_forces_of_graph(p, b, g, cutoff=5.0)
+            lo, hi = b["node_splits"][g], b["node_splits"][g + 1]
+            assert np.max(np.abs(force[lo:hi] - ref)) <= 1e-4 * max(float(np.max(np.abs(ref))), 1e-3 * scale), (seed, g)
+    assert energy.fused.last == "graph"
+
+
+def test_painn_route_falls_back_when_it_must():
+    from gcnn_keras_amd.literature import PAiNN
+    assert PAiNN.make_model(conv_args={"units": 64, "cutoff": None, "conv_pool": "sum"}, update_args={"units": 64},
+                            input_embedding={"node": {"input_dim": 95, "output_dim": 64}}).fused is None
+    assert PAiNN.make_model(pooling_args={"pooling_method": "mean"}).fused is None
+    assert PAiNN.make_model(output_embedding="node").fused is None
+    two = PAiNN.make_model(output_mlp={"use_bias": [True, True], "units": [128, 2], "activation": ["swish", "linear"]})
+    assert two.fused is not None and not two.fused.single_state     # forward fused, forces take the tape (two states)
+    b = synth.md17_like_batch(num_graphs=2, seed=1)
+    from gcnn_keras_amd.model.force import EnergyForceModel
+    out = EnergyForceModel(model_energy=two, energy_output=0, output_to_tensor=False)(mol_inputs(b))
+    assert tuple(out["energy"].shape) == (2, 2) and tuple(out["force"].values.shape) == (42, 3, 2)
