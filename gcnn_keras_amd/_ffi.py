@@ -53,7 +53,7 @@ _SIGNATURES = {
     "mp_segment_softmax_csr_f32": [P, c_int64, c_int64, P, P, c_int64, P, P],
     "mp_scatter_relational_f32": [c_int, P, c_int64, c_int64, P, P, c_int64, c_int64, P, P],
     "mp_dense_f32": [P, c_int64, c_int64, P, P, c_int64, c_int, c_float, P, P],
-    "mp_dense_ex_f32": [P, c_int64, c_int64, P, P, c_int64, c_int, c_float, c_int, c_int, c_float, P, P, P, P],
+    "mp_dense_ex_f32": [P, c_int64, c_int64, P, P, c_int64, c_int, c_float, c_int, c_int, c_float, P, P, P, P, P, P],
     "mp_activation_f32": [c_int, c_float, P, c_int64, P, P],
     "mp_softmax_rows_f32": [P, c_int64, c_int64, P, P],
     "mp_binary_f32": [c_int, P, P, P, P, c_int64, c_int64, c_int64, P, P],
@@ -84,7 +84,7 @@ _SIGNATURES = {
     "mp_painn_update_post_f32": [P, P, P, P, P, c_int64, P, P, P],
     "mp_painn_update_post_bwd_f32": [P, P, P, P, P, c_int64, P, P, P],
     "mp_painn_update_pre_bwd_f32": [P, P, P, P, P, P, P, c_int64, P, P, P],
-    "mp_edge_geometry_bwd_f32": [P, P, P, P, P, P, P, P, c_int64, c_int64, c_float, P, P],
+    "mp_edge_geometry_bwd_f32": [P, P, c_int, P, P, P, P, P, P, c_int64, c_int64, c_float, P, P],
     "mp_schnet_node_pack_f32": [P, c_int, c_int, P, P],
     "mp_schnet_node_residual_f32": [P, c_int64, P, P, P, P, P, P, c_int, P],
     "mp_schnet_node_in_f32": [P, c_int64, P, c_int, c_int, P, P, P, P, P, c_int, P],

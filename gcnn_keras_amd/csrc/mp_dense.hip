@@ -3,9 +3,10 @@
 // FP32-in / FP32-accumulate MFMA (v_mfma_f32_32x32x2_f32): exact f32 products, k-ordered fma chain, which keeps
 // the 1e-5 relative budget of BASELINE.json with room to spare (no xf32/TF32 on gfx950).  Generic in R, K, U
 // (SchNet (M,20)x(20,128), PaiNN (N,3,128)x(128,384), GCN (2708,1433)x(1433,64), heads with U = 1 or 7).
-// 64x64 output tile per 256-thread workgroup = 2x2 waves of one 32x32 accumulator each, BK = 32, operands staged
-// through LDS (A padded to 33 floats per row so the 32 rows a half-wave reads for one k hit 32 different banks,
-// W rows read contiguously), next tile's global loads issued before the MFMA loop of the current one.
+// 64x64 output tile per 256-thread workgroup = 2x2 waves of one 32x32 accumulator each, BK = 64, operands staged
+// through LDS (A padded to 65 floats per row so the 32 rows a half-wave reads for one k hit 32 different banks,
+// W rows read contiguously), next tile's global loads (16-B where the shape allows) issued before the MFMA loop of the
+// current one.
 // The fused SchNet kernels (mp_cfconv.hip / mp_schnet_node.hip) are the throughput path; this kernel serves
 // the layer-by-layer API and the GEMMs that are not worth fusing.
 #include "mp_common.h"
@@ -14,28 +15,39 @@ namespace {
 
 using floatx16 = __attribute__((ext_vector_type(16))) float;
 
-constexpr int BM = 64, BN = 64, BK = 32;
+constexpr int BM = 64, BN = 64, BK = 64;
 constexpr int A_LD = BK + 1;
 
 // Prologue / epilogue options of mp_dense_ex_f32 (the fused PaiNN pipeline and its reverse pass): IN_MODE 1 applies an
 // activation to x while the tile is staged (x holds a saved pre-activation: Dense(act) -> Dense becomes one launch per
 // GEMM with only the pre-activation kept), IN_MODE 2 multiplies x by act'(in_pre) (the reverse pass through an
 // activation, fused into the transposed-weight GEMM that follows it); `addend` (nullable, may alias `out`) is added to
-// the result after the output activation (residual adds / gradient accumulation).
+// the result after the output activation (residual adds / gradient accumulation).  The epilogue forms - `out_pre` keeps
+// the pre-activation next to the activated output, `grad_pre` multiplies the result by act'(saved pre-activation) - do
+// the same jobs at the PRODUCING GEMM, once per element, and are what the PaiNN pipeline uses: the prologue forms redo
+// the transcendental in every column-block workgroup and in front of its MFMAs (measured 21 vs 15 us per GEMM there).
 struct DenseExtra {
   int in_act;
   float in_alpha;
   const float* in_pre;   // (R, K) for IN_MODE 2
   const float* addend;   // (R, U) or null
+  float* out_pre;        // (R, U) or null: also store the pre-activation x W + b (kept for the reverse pass)
+  const float* grad_pre; // (R, U) or null: multiply the result by in_act'(grad_pre) (reverse pass through an activation
+                         // fused into the epilogue of the GEMM that produces the upstream gradient)
 };
 
-template <int IN_MODE>
+// VEC: K % 4 == 0, U % 4 == 0 and 16-B aligned operands: both tiles are fetched with 16-B loads (a quarter of the load
+// instructions of the scalar path, which stays for odd shapes such as GCN's 1433 input features or U = 1 heads).
+// The prologue transform is applied when the prefetched registers are written to LDS - i.e. AFTER the MFMA loop that
+// covers their latency - not where they are loaded (measured on the PaiNN chains: 21 -> ~9 us per (1344,128)x(128,384)
+// GEMM; applied at the load, the activation's first use of the data stalls the wave in front of its MFMAs).
+template <int IN_MODE, bool VEC>
 __global__ __launch_bounds__(256) void dense_mfma_kernel(const float* __restrict__ x, int64_t R, int64_t K,
                                                          const float* __restrict__ W, const float* __restrict__ b,
                                                          int64_t U, int act, float alpha, float* __restrict__ out,
                                                          DenseExtra ex) {
-  __shared__ float As[BM * A_LD];
-  __shared__ float Bs[BK * BN];
+  __shared__ __align__(16) float As[BM * A_LD];
+  __shared__ __align__(16) float Bs[BK * BN];
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -48,43 +60,89 @@ __global__ __launch_bounds__(256) void dense_mfma_kernel(const float* __restrict
 #pragma unroll
   for (int i = 0; i < 16; ++i) acc[i] = 0.0f;
 
-  float ra[8], rb[8];
+  constexpr int NV = (BM * BK) / (256 * 4);   // float4 per thread and tile (A and B tiles have the same size)
+  constexpr int NS = (BM * BK) / 256;         // floats per thread and tile, scalar path
+  float4 ra4[VEC ? NV : 1], rb4[VEC ? NV : 1], rp4[(VEC && IN_MODE == 2) ? NV : 1];
+  float ra[VEC ? 1 : NS], rb[VEC ? 1 : NS], rp[(!VEC && IN_MODE == 2) ? NS : 1];
   auto load_tile = [&](int64_t k0) {
+    if constexpr (VEC) {
 #pragma unroll
-    for (int i = 0; i < 8; ++i) {
-      const int idx = tid + i * 256;
-      const int ar = idx >> 5, ac = idx & 31;
-      const int64_t gr = row0 + ar, gk = k0 + ac;
-      float xv = (gr < R && gk < K) ? x[gr * K + gk] : 0.0f;
-      if constexpr (IN_MODE == 1) xv = (gr < R && gk < K) ? mp_apply_act(ex.in_act, ex.in_alpha, xv) : 0.0f;
-      if constexpr (IN_MODE == 2)
-        xv = (gr < R && gk < K) ? xv * mp_act_grad(ex.in_act, ex.in_alpha, ex.in_pre[gr * K + gk]) : 0.0f;
-      ra[i] = xv;
-      const int br = idx >> 6, bc = idx & 63;
-      const int64_t gk2 = k0 + br, gc = col0 + bc;
-      rb[i] = (gk2 < K && gc < U) ? W[gk2 * U + gc] : 0.0f;
+      for (int i = 0; i < NV; ++i) {
+        const int idx = tid + i * 256;
+        const int ar = idx / (BK / 4), ac = (idx % (BK / 4)) * 4;
+        const int64_t gr = row0 + ar, gk = k0 + ac;
+        const bool ok = gr < R && gk < K;
+        ra4[i] = ok ? *reinterpret_cast<const float4*>(x + gr * K + gk) : make_float4(0.f, 0.f, 0.f, 0.f);
+        if constexpr (IN_MODE == 2)
+          rp4[i] = ok ? *reinterpret_cast<const float4*>(ex.in_pre + gr * K + gk) : make_float4(0.f, 0.f, 0.f, 0.f);
+        const int br = idx / (BN / 4), bc = (idx % (BN / 4)) * 4;
+        const int64_t gk2 = k0 + br, gc = col0 + bc;
+        rb4[i] = (gk2 < K && gc < U) ? *reinterpret_cast<const float4*>(W + gk2 * U + gc) : make_float4(0.f, 0.f, 0.f, 0.f);
+      }
+    } else {
+#pragma unroll
+      for (int i = 0; i < NS; ++i) {
+        const int idx = tid + i * 256;
+        const int ar = idx / BK, ac = idx % BK;
+        const int64_t gr = row0 + ar, gk = k0 + ac;
+        const bool ok = gr < R && gk < K;
+        ra[i] = ok ? x[gr * K + gk] : 0.0f;
+        if constexpr (IN_MODE == 2) rp[i] = ok ? ex.in_pre[gr * K + gk] : 0.0f;
+        const int br = idx / BN, bc = idx % BN;
+        const int64_t gk2 = k0 + br, gc = col0 + bc;
+        rb[i] = (gk2 < K && gc < U) ? W[gk2 * U + gc] : 0.0f;
+      }
     }
   };
-  auto store_tile = [&]() {
+  // the staged value: act(x) / x * act'(pre); padding stays exactly 0 (act(0) need not be 0, act'(0) * 0 is)
+  auto prologue = [&](float xv, float pv, bool ok) -> float {
+    if constexpr (IN_MODE == 1) return ok ? mp_apply_act(ex.in_act, ex.in_alpha, xv) : 0.0f;
+    if constexpr (IN_MODE == 2) return xv * mp_act_grad(ex.in_act, ex.in_alpha, pv);
+    return xv;
+  };
+  auto store_tile = [&](int64_t k0) {
+    if constexpr (VEC) {
 #pragma unroll
-    for (int i = 0; i < 8; ++i) {
-      const int idx = tid + i * 256;
-      As[(idx >> 5) * A_LD + (idx & 31)] = ra[i];
-      Bs[idx] = rb[i];
+      for (int i = 0; i < NV; ++i) {
+        const int idx = tid + i * 256;
+        const int ar = idx / (BK / 4), ac = (idx % (BK / 4)) * 4;
+        const bool ok = (row0 + ar) < R && (k0 + ac) < K;
+        float* d = As + ar * A_LD + ac;
+        const float4 pv = (IN_MODE == 2) ? rp4[i] : make_float4(0.f, 0.f, 0.f, 0.f);
+        d[0] = prologue(ra4[i].x, pv.x, ok);
+        d[1] = prologue(ra4[i].y, pv.y, ok);
+        d[2] = prologue(ra4[i].z, pv.z, ok);
+        d[3] = prologue(ra4[i].w, pv.w, ok);
+        *reinterpret_cast<float4*>(Bs + idx * 4) = rb4[i];
+      }
+    } else {
+#pragma unroll
+      for (int i = 0; i < NS; ++i) {
+        const int idx = tid + i * 256;
+        const bool ok = (row0 + idx / BK) < R && (k0 + idx % BK) < K;
+        As[(idx / BK) * A_LD + (idx % BK)] = prologue(ra[i], (IN_MODE == 2) ? rp[i] : 0.0f, ok);
+        Bs[idx] = rb[i];
+      }
     }
   };
 
   const int64_t ktiles = (K + BK - 1) / BK;
   load_tile(0);
   for (int64_t t = 0; t < ktiles; ++t) {
-    store_tile();
+    store_tile(t * BK);
     __syncthreads();
     if (t + 1 < ktiles) load_tile((t + 1) * BK);
+    const int64_t left = K - t * BK;
+    const int steps = left >= BK ? BK / 2 : static_cast<int>((left + 1) / 2);   // k pairs that hold data
     const float* a_ptr = As + (wr * 32 + (lane & 31)) * A_LD + (lane >> 5);
     const float* b_ptr = Bs + (lane >> 5) * BN + wc * 32 + (lane & 31);
+    if (steps == BK / 2) {
 #pragma unroll
-    for (int kk = 0; kk < BK / 2; ++kk) {
-      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a_ptr[kk * 2], b_ptr[kk * 2 * BN], acc, 0, 0, 0);
+      for (int kk = 0; kk < BK / 2; ++kk)
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a_ptr[kk * 2], b_ptr[kk * 2 * BN], acc, 0, 0, 0);
+    } else {   // last, partial k tile (zero padded up to an even k)
+      for (int kk = 0; kk < steps; ++kk)
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a_ptr[kk * 2], b_ptr[kk * 2 * BN], acc, 0, 0, 0);
     }
     __syncthreads();
   }
@@ -96,12 +154,25 @@ __global__ __launch_bounds__(256) void dense_mfma_kernel(const float* __restrict
     for (int r = 0; r < 16; ++r) {
       const int64_t row = row0 + wr * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
       if (row < R) {
-        float v = mp_apply_act(act, alpha, acc[r] + bias);
+        const float pre = acc[r] + bias;
+        if (ex.out_pre) ex.out_pre[row * U + col] = pre;
+        float v = mp_apply_act(act, alpha, pre);
+        if (ex.grad_pre) v *= mp_act_grad(ex.in_act, ex.in_alpha, ex.grad_pre[row * U + col]);
         if (ex.addend) v += ex.addend[row * U + col];
         out[row * U + col] = v;
       }
     }
   }
+}
+
+template <int IN_MODE>
+void launch_dense(dim3 grid, hipStream_t s, const float* x, int64_t R, int64_t K, const float* W, const float* b,
+                  int64_t U, int act, float alpha, float* out, const DenseExtra& ex) {
+  const bool vec = (K % 4 == 0) && (U % 4 == 0) && (reinterpret_cast<uintptr_t>(x) % 16 == 0) &&
+                   (reinterpret_cast<uintptr_t>(W) % 16 == 0) &&
+                   (ex.in_pre == nullptr || reinterpret_cast<uintptr_t>(ex.in_pre) % 16 == 0);
+  if (vec) dense_mfma_kernel<IN_MODE, true><<<grid, 256, 0, s>>>(x, R, K, W, b, U, act, alpha, out, ex);
+  else dense_mfma_kernel<IN_MODE, false><<<grid, 256, 0, s>>>(x, R, K, W, b, U, act, alpha, out, ex);
 }
 
 __global__ void activation_kernel(int act, float alpha, const float* __restrict__ x, int64_t n,
@@ -184,14 +255,14 @@ int mp_dense_f32(const float* x, int64_t R, int64_t K, const float* W, const flo
   const int64_t gy = mp::ceil_div(R, BM), gx = mp::ceil_div(U, BN);
   MP_REQUIRE(gx <= 65535 && gy < (int64_t{1} << 31), "mp_dense_f32: grid too large");
   dim3 grid(static_cast<unsigned>(gy), static_cast<unsigned>(gx));
-  dense_mfma_kernel<0><<<grid, 256, 0, mp::as_stream(stream)>>>(x, R, K, W, b, U, act, act_alpha, out,
-                                                                DenseExtra{0, 0.0f, nullptr, nullptr});
+  launch_dense<0>(grid, mp::as_stream(stream), x, R, K, W, b, U, act, act_alpha, out,
+                  DenseExtra{0, 0.0f, nullptr, nullptr, nullptr, nullptr});
   return mp::check_launch("mp_dense_f32");
 }
 
 int mp_dense_ex_f32(const float* x, int64_t R, int64_t K, const float* W, const float* b, int64_t U, int act,
                     float act_alpha, int in_mode, int in_act, float in_alpha, const float* in_pre, const float* addend,
-                    float* out, mpStream_t stream) {
+                    float* out_pre, const float* grad_pre, float* out, mpStream_t stream) {
   MP_REQUIRE(R >= 0 && K >= 1 && U >= 1, "mp_dense_ex_f32: bad sizes R=%lld K=%lld U=%lld", (long long)R, (long long)K,
              (long long)U);
   MP_REQUIRE(act >= MP_ACT_LINEAR && act <= MP_ACT_SOFTPLUS2 && in_act >= MP_ACT_LINEAR && in_act <= MP_ACT_SOFTPLUS2,
@@ -202,11 +273,11 @@ int mp_dense_ex_f32(const float* x, int64_t R, int64_t K, const float* W, const 
   const int64_t gy = mp::ceil_div(R, BM), gx = mp::ceil_div(U, BN);
   MP_REQUIRE(gx <= 65535 && gy < (int64_t{1} << 31), "mp_dense_ex_f32: grid too large");
   dim3 grid(static_cast<unsigned>(gy), static_cast<unsigned>(gx));
-  const DenseExtra ex{in_act, in_alpha, in_pre, addend};
+  const DenseExtra ex{in_act, in_alpha, in_pre, addend, out_pre, grad_pre};
   hipStream_t s = mp::as_stream(stream);
-  if (in_mode == 0) dense_mfma_kernel<0><<<grid, 256, 0, s>>>(x, R, K, W, b, U, act, act_alpha, out, ex);
-  else if (in_mode == 1) dense_mfma_kernel<1><<<grid, 256, 0, s>>>(x, R, K, W, b, U, act, act_alpha, out, ex);
-  else dense_mfma_kernel<2><<<grid, 256, 0, s>>>(x, R, K, W, b, U, act, act_alpha, out, ex);
+  if (in_mode == 0) launch_dense<0>(grid, s, x, R, K, W, b, U, act, act_alpha, out, ex);
+  else if (in_mode == 1) launch_dense<1>(grid, s, x, R, K, W, b, U, act, act_alpha, out, ex);
+  else launch_dense<2>(grid, s, x, R, K, W, b, U, act, act_alpha, out, ex);
   return mp::check_launch("mp_dense_ex_f32");
 }
 

@@ -39,12 +39,25 @@ __device__ __forceinline__ float wave_sum(float v) {
 }
 
 // ---------------------------------------------------------------------------------------------------- stage 0
-// Edge continuation of the index pass: EdgeDirectionNormalized (geom.py:331-378, divide_no_nan), BesselBasisLayer
-// (geom.py:772-785) with the arithmetic of bessel_basis_kernel (csrc/mp_elementwise.hip), its derivative as in
-// bessel_grad_kernel (csrc/mp_backward.hip), CosCutOffEnvelope (geom.py:831-837) and its derivative.
+// Edge continuation of the index pass: EdgeDirectionNormalized (geom.py:331-378, divide_no_nan).
 struct PainnEdgeExtra {
   static constexpr bool active = true;
   float* rij;         // (M,3)
+  __device__ __forceinline__ void operator()(int64_t e, float dx, float dy, float dz, float s) const {
+    const float inv = s == 0.0f ? 0.0f : 1.0f / s;
+    rij[e * 3 + 0] = dx * inv;
+    rij[e * 3 + 1] = dy * inv;
+    rij[e * 3 + 2] = dz * inv;
+  }
+};
+
+// BesselBasisLayer (geom.py:772-785) with the arithmetic of bessel_basis_kernel (csrc/mp_elementwise.hip), its derivative
+// as in bessel_grad_kernel (csrc/mp_backward.hip), CosCutOffEnvelope (geom.py:831-837) and its derivative: one thread per
+// (edge, basis function) - the sin / cos evaluations are the cost, and M x B threads fill the chip where M threads with a
+// serial loop over B do not (measured 12-17 us for the one-thread-per-edge form at 20 k edges).
+struct PainnBasisArgs {
+  const float* dist;  // (M)
+  int64_t M;
   const float* freq;  // (B)
   int B;
   float inv_cutoff;
@@ -55,36 +68,41 @@ struct PainnEdgeExtra {
   float cos_cutoff;   // <= 0: no envelope
   float* env;         // (M) or null
   float* envd;        // (M) or null
-  __device__ __forceinline__ void operator()(int64_t e, float dx, float dy, float dz, float s) const {
-    const float inv = s == 0.0f ? 0.0f : 1.0f / s;
-    rij[e * 3 + 0] = dx * inv;
-    rij[e * 3 + 1] = dy * inv;
-    rij[e * 3 + 2] = dz * inv;
-    const float xs = s * inv_cutoff;
-    const float xp1 = ipow(xs, p - 1);
-    const float envp = 1.0f / xs + a * xp1 + b * (xp1 * xs) + c * (xp1 * xs * xs);
+};
+
+__global__ __launch_bounds__(256) void painn_basis_kernel(PainnBasisArgs q) {
+  const int64_t total = q.M * q.B;
+  const int64_t stride = static_cast<int64_t>(gridDim.x) * blockDim.x;
+  for (int64_t t = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x; t < total; t += stride) {
+    const int64_t e = t / q.B;
+    const int k = static_cast<int>(t % q.B);
+    const float s = q.dist[e];
+    const float xs = s * q.inv_cutoff;
+    const float xp1 = ipow(xs, q.p - 1);
+    const float envp = 1.0f / xs + q.a * xp1 + q.b * (xp1 * xs) + q.c * (xp1 * xs * xs);
     const float cut = xs < 1.0f ? envp : 0.0f;
-    const bool inside = xs < 1.0f && xs > 0.0f;
-    float denv = 0.0f, env_in = 0.0f;
-    if (rbfd != nullptr && inside) {
-      const float xp2 = ipow(xs, p - 2);
-      const float xq1 = xp2 * xs;
-      env_in = 1.0f / xs + a * xq1 + b * (xq1 * xs) + c * (xq1 * xs * xs);
-      denv = -1.0f / (xs * xs) + a * (p - 1) * xp2 + b * p * xq1 + c * (p + 1) * (xq1 * xs);
+    const float f = q.freq[k];
+    const float sn = sinf(f * xs);
+    q.rbf[t] = cut * sn;
+    if (q.rbfd != nullptr) {
+      float dv = 0.0f;
+      if (xs < 1.0f && xs > 0.0f) {
+        const float xp2 = ipow(xs, q.p - 2);
+        const float xq1 = xp2 * xs;
+        const float env_in = 1.0f / xs + q.a * xq1 + q.b * (xq1 * xs) + q.c * (xq1 * xs * xs);
+        const float denv = -1.0f / (xs * xs) + q.a * (q.p - 1) * xp2 + q.b * q.p * xq1 + q.c * (q.p + 1) * (xq1 * xs);
+        dv = (denv * sn + env_in * f * cosf(f * xs)) * q.inv_cutoff;
+      }
+      q.rbfd[t] = dv;
     }
-    for (int k = 0; k < B; ++k) {
-      const float f = freq[k];
-      rbf[e * B + k] = cut * sinf(f * xs);
-      if (rbfd != nullptr) rbfd[e * B + k] = inside ? (denv * sinf(f * xs) + env_in * f * cosf(f * xs)) * inv_cutoff : 0.0f;
-    }
-    if (env != nullptr) {
-      const float scale = 3.14159265358979323846f / cos_cutoff;
-      const float v = fminf(fmaxf(s, -cos_cutoff), cos_cutoff);
-      env[e] = (cosf(v * scale) + 1.0f) * 0.5f;
-      if (envd != nullptr) envd[e] = (s > -cos_cutoff && s < cos_cutoff) ? -0.5f * scale * sinf(s * scale) : 0.0f;
+    if (k == 0 && q.env != nullptr) {
+      const float scale = 3.14159265358979323846f / q.cos_cutoff;
+      const float v = fminf(fmaxf(s, -q.cos_cutoff), q.cos_cutoff);
+      q.env[e] = (cosf(v * scale) + 1.0f) * 0.5f;
+      if (q.envd != nullptr) q.envd[e] = (s > -q.cos_cutoff && s < q.cos_cutoff) ? -0.5f * scale * sinf(s * scale) : 0.0f;
     }
   }
-};
+}
 
 struct PainnNodeInit {
   const float* numbers;  // (N) float node numbers (Keras Embedding casts to int32)
@@ -137,105 +155,99 @@ struct PainnMsgArgs {
   int B;
 };
 
-// One wave per receiving node (receiver-parallel over the CSR, sequential in edge order = the order tf.math.segment_sum
-// uses after the stable sort: deterministic).  Lane l holds features 2l, 2l+1 as one register pair, so every gathered row
-// part is ONE 512-B wave read and the filter / product arithmetic is packed FP32 (v_pk_fma_f32).  Edges are taken four at
-// a time: the four senders' rows are all requested before the first is used (the per-edge chain perm -> send -> row is
-// otherwise one dependent L2 round trip per edge).  Wave-uniform data (edge id, sender id, rbf row, r_ij, envelope) is
-// fetched with scalar loads.
+// TWO waves per receiving node, one per half of the 128 features (lane = one feature): receiver-parallel over the CSR,
+// sequential in edge order = the order tf.math.segment_sum uses after the stable sort, so the result is deterministic.
+// At MD17 / QM9 batch sizes the kernel is latency bound (1344 nodes x ~15 edges), so it is built to keep loads in flight:
+//  * the edge ids and sender ids of up to 64 edges of the node are fetched with ONE coalesced load each into a VGPR
+//    (lane = edge) and handed out with v_readlane - no dependent scalar-load chain perm -> send -> row per edge;
+//  * eight senders' rows (s: 3 values, v: 3 values per lane) are requested before the first is used;
+//  * half the features per wave halves the registers (60 filter weights) and doubles the waves per node.
+// Wave-uniform data (rbf row, r_ij, envelope) is fetched with scalar loads.
 template <int BT>
 __global__ __launch_bounds__(256) void painn_message_kernel(PainnMsgArgs a) {
   constexpr int MAXB = BT > 0 ? BT : 32;
-  constexpr int EC = 4;
+  constexpr int EC = 8;
   const int lane = threadIdx.x & 63;
   const int B = BT > 0 ? BT : a.B;
-  float2 w[3][MAXB], bias[3];
+  const int64_t nwaves = (static_cast<int64_t>(gridDim.x) * blockDim.x) >> 6;
+  const int64_t wave0 = (static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x) >> 6;
+  const int half = __builtin_amdgcn_readfirstlane(static_cast<int>(wave0 & 1));   // nwaves is even: fixed per wave
+  const int f0 = half * 64 + lane;                                                 // this lane's feature
+  float w[3][MAXB], bias[3];
 #pragma unroll
   for (int p = 0; p < 3; ++p) {
 #pragma unroll
-    for (int k = 0; k < MAXB; ++k)
-      w[p][k] = k < B ? *reinterpret_cast<const float2*>(a.Ww + k * 3 * F + p * F + 2 * lane) : make_float2(0.f, 0.f);
-    bias[p] = a.bw ? *reinterpret_cast<const float2*>(a.bw + p * F + 2 * lane) : make_float2(0.f, 0.f);
+    for (int k = 0; k < MAXB; ++k) w[p][k] = k < B ? a.Ww[k * 3 * F + p * F + f0] : 0.0f;
+    bias[p] = a.bw ? a.bw[p * F + f0] : 0.0f;
   }
-  const int64_t nwaves = (static_cast<int64_t>(gridDim.x) * blockDim.x) >> 6;
-  for (int64_t n0 = (static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x) >> 6; n0 < a.N; n0 += nwaves) {
-    const int n = __builtin_amdgcn_readfirstlane(static_cast<int>(n0));
+  for (int64_t wv = wave0; wv < 2 * a.N; wv += nwaves) {
+    const int n = __builtin_amdgcn_readfirstlane(static_cast<int>(wv >> 1));
     int e_lo = a.ptr[n], e_hi = a.ptr[n + 1];
     e_lo = e_lo < 0 ? 0 : (e_lo > a.M ? static_cast<int>(a.M) : e_lo);
     e_hi = e_hi < e_lo ? e_lo : (e_hi > a.M ? static_cast<int>(a.M) : e_hi);
-    float2 ds = make_float2(0.f, 0.f), dv[3];
-#pragma unroll
-    for (int k = 0; k < 3; ++k) dv[k] = make_float2(0.f, 0.f);
-    for (int e0 = e_lo; e0 < e_hi; e0 += EC) {
-      int r[EC];
-      float2 sj[EC][3], vj[EC][3];
-#pragma unroll
-      for (int u = 0; u < EC; ++u) {
-        const int e = e0 + u < e_hi ? e0 + u : e_hi - 1;   // the tail repeats the last edge (loads only)
-        r[u] = a.perm ? a.perm[e] : e;
-        int j = a.send[r[u]];
-        j = j < 0 ? 0 : (j >= a.N ? static_cast<int>(a.N) - 1 : j);
-        const float* srow = a.s + static_cast<int64_t>(j) * 3 * F + 2 * lane;
-        const float* vrow = a.v + static_cast<int64_t>(j) * 3 * F + 2 * lane;
-#pragma unroll
-        for (int p = 0; p < 3; ++p) {
-          sj[u][p] = *reinterpret_cast<const float2*>(srow + p * F);
-          vj[u][p] = *reinterpret_cast<const float2*>(vrow + p * F);
-        }
+    float ds = 0.0f, dv[3] = {0.0f, 0.0f, 0.0f};
+    for (int base = e_lo; base < e_hi; base += 64) {
+      const int cnt = e_hi - base < 64 ? e_hi - base : 64;
+      int my_r = 0, my_j = 0;
+      if (lane < cnt) {
+        my_r = a.perm ? a.perm[base + lane] : base + lane;
+        my_j = a.send[my_r];
+        my_j = my_j < 0 ? 0 : (my_j >= a.N ? static_cast<int>(a.N) - 1 : my_j);
       }
+      for (int u0 = 0; u0 < cnt; u0 += EC) {
+        float sj[EC][3], vj[EC][3];
 #pragma unroll
-      for (int u = 0; u < EC; ++u) {
-        if (e0 + u < e_hi) {   // wave-uniform
-          const float* rb = a.rbf + static_cast<int64_t>(r[u]) * B;
-          float2 f[3];
-#pragma unroll
-          for (int p = 0; p < 3; ++p) f[p] = make_float2(0.f, 0.f);
-#pragma unroll
-          for (int k = 0; k < MAXB; ++k) {
-            if (k < B) {
-              const float x = rb[k];
-#pragma unroll
-              for (int p = 0; p < 3; ++p) {
-                f[p].x = fmaf(x, w[p][k].x, f[p].x);
-                f[p].y = fmaf(x, w[p][k].y, f[p].y);
-              }
-            }
-          }
-          const float envv = a.env ? a.env[r[u]] : 1.0f;
-          float2 sw[3];
+        for (int u = 0; u < EC; ++u) {
+          const int slot = u0 + u < cnt ? u0 + u : cnt - 1;   // the tail repeats the last edge (loads only)
+          const int j = __builtin_amdgcn_readlane(my_j, slot);
+          const float* srow = a.s + static_cast<int64_t>(j) * 3 * F + f0;
+          const float* vrow = a.v + static_cast<int64_t>(j) * 3 * F + f0;
 #pragma unroll
           for (int p = 0; p < 3; ++p) {
-            float wx = f[p].x + bias[p].x, wy = f[p].y + bias[p].y;   // Dense: x W + b
-            if (a.env) { wx *= envv; wy *= envv; }                    // lay_mult_cutoff([w, envelope])
-            sw[p].x = sj[u][p].x * wx;                                // lay_mult([s, w])
-            sw[p].y = sj[u][p].y * wy;
+            sj[u][p] = srow[p * F];
+            vj[u][p] = vrow[p * F];
           }
-          ds.x += sw[0].x;
-          ds.y += sw[0].y;
+        }
 #pragma unroll
-          for (int k = 0; k < 3; ++k) {
-            const float rk = a.rij[static_cast<int64_t>(r[u]) * 3 + k];
-            dv[k].x += sw[1].x * vj[u][k].x + sw[2].x * rk;           // (sw2 * v_j) + (sw3 * r_ij)
-            dv[k].y += sw[1].y * vj[u][k].y + sw[2].y * rk;
+        for (int u = 0; u < EC; ++u) {
+          if (u0 + u < cnt) {   // wave-uniform
+            const int r = __builtin_amdgcn_readlane(my_r, u0 + u);
+            const float* rb = a.rbf + static_cast<int64_t>(r) * B;
+            float f[3] = {0.0f, 0.0f, 0.0f};
+#pragma unroll
+            for (int k = 0; k < MAXB; ++k) {
+              if (k < B) {
+                const float x = rb[k];
+#pragma unroll
+                for (int p = 0; p < 3; ++p) f[p] = fmaf(x, w[p][k], f[p]);
+              }
+            }
+            const float envv = a.env ? a.env[r] : 1.0f;
+            float sw[3];
+#pragma unroll
+            for (int p = 0; p < 3; ++p) {
+              float wv_ = f[p] + bias[p];            // Dense: x W + b
+              if (a.env) wv_ *= envv;                // lay_mult_cutoff([w, envelope])
+              sw[p] = sj[u][p] * wv_;                // lay_mult([s, w])
+            }
+            ds += sw[0];
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+              const float rk = a.rij[static_cast<int64_t>(r) * 3 + k];
+              dv[k] += sw[1] * vj[u][k] + sw[2] * rk;   // (sw2 * v_j) + (sw3 * r_ij)
+            }
           }
         }
       }
     }
     if (a.z_in) {   // residual adds of PAiNN.py:126-127 fused: z + ds, v + dv
-      const float2 z = *reinterpret_cast<const float2*>(a.z_in + static_cast<int64_t>(n) * F + 2 * lane);
-      ds.x += z.x;
-      ds.y += z.y;
+      ds += a.z_in[static_cast<int64_t>(n) * F + f0];
 #pragma unroll
-      for (int k = 0; k < 3; ++k) {
-        const float2 vo = *reinterpret_cast<const float2*>(a.v + (static_cast<int64_t>(n) * 3 + k) * F + 2 * lane);
-        dv[k].x += vo.x;
-        dv[k].y += vo.y;
-      }
+      for (int k = 0; k < 3; ++k) dv[k] += a.v[(static_cast<int64_t>(n) * 3 + k) * F + f0];
     }
-    *reinterpret_cast<float2*>(a.ds + static_cast<int64_t>(n) * F + 2 * lane) = ds;
+    a.ds[static_cast<int64_t>(n) * F + f0] = ds;
 #pragma unroll
-    for (int k = 0; k < 3; ++k)
-      *reinterpret_cast<float2*>(a.dv + (static_cast<int64_t>(n) * 3 + k) * F + 2 * lane) = dv[k];
+    for (int k = 0; k < 3; ++k) a.dv[(static_cast<int64_t>(n) * 3 + k) * F + f0] = dv[k];
   }
 }
 
@@ -257,136 +269,141 @@ struct PainnMsgBwdArgs {
   const float* g_dv;     // (N, 3, F) upstream gradient of dv (= dE/dv')
   float* g_s;            // (N, 3F)   out
   float* g_v;            // (N, 3, F) out = g_dv (residual path) + message path; null: not needed (first block)
-  float* g_d;            // (M)    dE/dd_e: written (accumulate = 0) or added to
-  float* g_rij;          // (M, 3) dE/dr_ij
+  float* g_d;            // (2, M)    dE/dd_e per feature half: written (accumulate = 0) or added to
+  float* g_rij;          // (2, M, 3) dE/dr_ij per feature half
   int accumulate;
   int64_t N, M;
   int B;
 };
 
-// One wave per SENDING node j: s_j and v_j are the wave's own rows, the upstream gradients are gathered from the
-// receivers of j's edges, the gradients w.r.t. s_j and v_j accumulate in registers in edge order (deterministic) and are
-// written once.  Per edge the wave also reduces four scalars (dE/dd_e, dE/dr_ij) over its 128 features; each edge belongs
-// to exactly one sender, so the per-edge accumulators are plain read-modify-writes.
+// Two waves per SENDING node j (one per feature half, lane = one feature): s_j and v_j are the wave's own values, the
+// upstream gradients are gathered from the receivers of j's edges (edge / receiver ids of up to 64 edges held lane-wise,
+// four receivers' rows in flight), the gradients w.r.t. s_j and v_j accumulate in registers in edge order
+// (deterministic) and are written once.  Per edge the wave also reduces four scalars (dE/dd_e, dE/dr_ij) over its 64
+// features; the two halves of a node write separate slices g_d[half], g_rij[half] (each edge has exactly one sender, so
+// within a slice the per-edge accumulators are plain read-modify-writes); the geometry kernel adds the slices.
 template <int BT>
 __global__ __launch_bounds__(256) void painn_message_bwd_kernel(PainnMsgBwdArgs a) {
   constexpr int MAXB = BT > 0 ? BT : 32;
+  constexpr int EC = 4;
   const int lane = threadIdx.x & 63;
   const int B = BT > 0 ? BT : a.B;
-  float2 w[3][MAXB], bias[3];
+  const int64_t nwaves = (static_cast<int64_t>(gridDim.x) * blockDim.x) >> 6;
+  const int64_t wave0 = (static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x) >> 6;
+  const int half = __builtin_amdgcn_readfirstlane(static_cast<int>(wave0 & 1));
+  const int f0 = half * 64 + lane;
+  float* const g_d = a.g_d + static_cast<int64_t>(half) * a.M;
+  float* const g_rij = a.g_rij + static_cast<int64_t>(half) * a.M * 3;
+  float w[3][MAXB], bias[3];
 #pragma unroll
   for (int p = 0; p < 3; ++p) {
 #pragma unroll
-    for (int k = 0; k < MAXB; ++k)
-      w[p][k] = k < B ? *reinterpret_cast<const float2*>(a.Ww + k * 3 * F + p * F + 2 * lane) : make_float2(0.f, 0.f);
-    bias[p] = a.bw ? *reinterpret_cast<const float2*>(a.bw + p * F + 2 * lane) : make_float2(0.f, 0.f);
+    for (int k = 0; k < MAXB; ++k) w[p][k] = k < B ? a.Ww[k * 3 * F + p * F + f0] : 0.0f;
+    bias[p] = a.bw ? a.bw[p * F + f0] : 0.0f;
   }
-  const int64_t nwaves = (static_cast<int64_t>(gridDim.x) * blockDim.x) >> 6;
-  for (int64_t n0 = (static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x) >> 6; n0 < a.N; n0 += nwaves) {
-    const int j = __builtin_amdgcn_readfirstlane(static_cast<int>(n0));
+  for (int64_t wv = wave0; wv < 2 * a.N; wv += nwaves) {
+    const int j = __builtin_amdgcn_readfirstlane(static_cast<int>(wv >> 1));
     int e_lo = a.ptr1[j], e_hi = a.ptr1[j + 1];
     e_lo = e_lo < 0 ? 0 : (e_lo > a.M ? static_cast<int>(a.M) : e_lo);
     e_hi = e_hi < e_lo ? e_lo : (e_hi > a.M ? static_cast<int>(a.M) : e_hi);
-    float2 sj[3], vj[3], gs[3], gv[3];
+    float sj[3], vj[3], gs[3] = {0.0f, 0.0f, 0.0f}, gv[3] = {0.0f, 0.0f, 0.0f};
 #pragma unroll
     for (int p = 0; p < 3; ++p) {
-      sj[p] = *reinterpret_cast<const float2*>(a.s + static_cast<int64_t>(j) * 3 * F + p * F + 2 * lane);
-      vj[p] = *reinterpret_cast<const float2*>(a.v + static_cast<int64_t>(j) * 3 * F + p * F + 2 * lane);
-      gs[p] = make_float2(0.f, 0.f);
-      gv[p] = make_float2(0.f, 0.f);
+      sj[p] = a.s[static_cast<int64_t>(j) * 3 * F + p * F + f0];
+      vj[p] = a.v[static_cast<int64_t>(j) * 3 * F + p * F + f0];
     }
-    for (int e = e_lo; e < e_hi; ++e) {
-      const int r = a.perm1 ? a.perm1[e] : e;   // wave-uniform
-      int i = a.recv[r];
-      i = i < 0 ? 0 : (i >= a.N ? static_cast<int>(a.N) - 1 : i);
-      const float2 gz = *reinterpret_cast<const float2*>(a.g_ds + static_cast<int64_t>(i) * F + 2 * lane);
-      float2 gdv[3];
-#pragma unroll
-      for (int k = 0; k < 3; ++k)
-        gdv[k] = *reinterpret_cast<const float2*>(a.g_dv + (static_cast<int64_t>(i) * 3 + k) * F + 2 * lane);
-      const float* rb = a.rbf + static_cast<int64_t>(r) * B;
-      const float* rd = a.rbfd + static_cast<int64_t>(r) * B;
-      float2 f[3], fd[3];
-#pragma unroll
-      for (int p = 0; p < 3; ++p) {
-        f[p] = make_float2(0.f, 0.f);
-        fd[p] = make_float2(0.f, 0.f);
+    for (int base = e_lo; base < e_hi; base += 64) {
+      const int cnt = e_hi - base < 64 ? e_hi - base : 64;
+      int my_r = 0, my_i = 0;
+      if (lane < cnt) {
+        my_r = a.perm1 ? a.perm1[base + lane] : base + lane;
+        my_i = a.recv[my_r];
+        my_i = my_i < 0 ? 0 : (my_i >= a.N ? static_cast<int>(a.N) - 1 : my_i);
       }
+      for (int u0 = 0; u0 < cnt; u0 += EC) {
+        float gz[EC], gdv[EC][3];
 #pragma unroll
-      for (int k = 0; k < MAXB; ++k) {
-        if (k < B) {
-          const float x = rb[k], xd = rd[k];
+        for (int u = 0; u < EC; ++u) {
+          const int slot = u0 + u < cnt ? u0 + u : cnt - 1;
+          const int i = __builtin_amdgcn_readlane(my_i, slot);
+          gz[u] = a.g_ds[static_cast<int64_t>(i) * F + f0];
 #pragma unroll
-          for (int p = 0; p < 3; ++p) {
-            f[p].x = fmaf(x, w[p][k].x, f[p].x);
-            f[p].y = fmaf(x, w[p][k].y, f[p].y);
-            fd[p].x = fmaf(xd, w[p][k].x, fd[p].x);
-            fd[p].y = fmaf(xd, w[p][k].y, fd[p].y);
+          for (int k = 0; k < 3; ++k) gdv[u][k] = a.g_dv[(static_cast<int64_t>(i) * 3 + k) * F + f0];
+        }
+#pragma unroll
+        for (int u = 0; u < EC; ++u) {
+          if (u0 + u < cnt) {   // wave-uniform
+            const int r = __builtin_amdgcn_readlane(my_r, u0 + u);
+            const float* rb = a.rbf + static_cast<int64_t>(r) * B;
+            const float* rd = a.rbfd + static_cast<int64_t>(r) * B;
+            float f[3] = {0.0f, 0.0f, 0.0f}, fd[3] = {0.0f, 0.0f, 0.0f};
+#pragma unroll
+            for (int k = 0; k < MAXB; ++k) {
+              if (k < B) {
+                const float x = rb[k], xd = rd[k];
+#pragma unroll
+                for (int p = 0; p < 3; ++p) {
+                  f[p] = fmaf(x, w[p][k], f[p]);
+                  fd[p] = fmaf(xd, w[p][k], fd[p]);
+                }
+              }
+            }
+            float rk[3];
+#pragma unroll
+            for (int k = 0; k < 3; ++k) rk[k] = a.rij[static_cast<int64_t>(r) * 3 + k];
+            // filter and its derivative w.r.t. the distance (the envelope is a second factor: product rule)
+            float wf[3], wd[3];
+            const float envv = a.env ? a.env[r] : 1.0f;
+            const float envdv = (a.env && a.envd) ? a.envd[r] : 0.0f;
+#pragma unroll
+            for (int p = 0; p < 3; ++p) {
+              const float wx = f[p] + bias[p];
+              wf[p] = a.env ? wx * envv : wx;
+              wd[p] = a.env ? fd[p] * envv + wx * envdv : fd[p];
+            }
+            // upstream gradients of the three parts of sw = s_j * w
+            float gsw[3];
+            gsw[0] = gz[u];
+            gsw[1] = gdv[u][0] * vj[0] + gdv[u][1] * vj[1] + gdv[u][2] * vj[2];
+            gsw[2] = gdv[u][0] * rk[0] + gdv[u][1] * rk[1] + gdv[u][2] * rk[2];
+            float gd = 0.0f;
+#pragma unroll
+            for (int p = 0; p < 3; ++p) {
+              gs[p] += gsw[p] * wf[p];
+              gd += gsw[p] * sj[p] * wd[p];
+            }
+            const float sw2 = sj[1] * wf[1], sw3 = sj[2] * wf[2];
+            float gr[3];
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+              gv[k] += gdv[u][k] * sw2;
+              gr[k] = gdv[u][k] * sw3;
+            }
+            gd = wave_sum(gd);
+#pragma unroll
+            for (int k = 0; k < 3; ++k) gr[k] = wave_sum(gr[k]);
+            if (lane == 0) {
+              if (a.accumulate) {
+                g_d[r] += gd;
+#pragma unroll
+                for (int k = 0; k < 3; ++k) g_rij[static_cast<int64_t>(r) * 3 + k] += gr[k];
+              } else {
+                g_d[r] = gd;
+#pragma unroll
+                for (int k = 0; k < 3; ++k) g_rij[static_cast<int64_t>(r) * 3 + k] = gr[k];
+              }
+            }
           }
         }
       }
-      float rk[3];
-#pragma unroll
-      for (int k = 0; k < 3; ++k) rk[k] = a.rij[static_cast<int64_t>(r) * 3 + k];
-      // filter and its derivative w.r.t. the distance (the envelope is a second factor: product rule)
-      float2 wf[3], wd[3];
-      const float envv = a.env ? a.env[r] : 1.0f;
-      const float envdv = (a.env && a.envd) ? a.envd[r] : 0.0f;
-#pragma unroll
-      for (int p = 0; p < 3; ++p) {
-        const float wx = f[p].x + bias[p].x, wy = f[p].y + bias[p].y;
-        wf[p].x = a.env ? wx * envv : wx;
-        wf[p].y = a.env ? wy * envv : wy;
-        wd[p].x = a.env ? fd[p].x * envv + wx * envdv : fd[p].x;
-        wd[p].y = a.env ? fd[p].y * envv + wy * envdv : fd[p].y;
-      }
-      // upstream gradients of the three parts of sw = s_j * w
-      float2 gsw[3];
-      gsw[0] = gz;
-      gsw[1].x = gdv[0].x * vj[0].x + gdv[1].x * vj[1].x + gdv[2].x * vj[2].x;
-      gsw[1].y = gdv[0].y * vj[0].y + gdv[1].y * vj[1].y + gdv[2].y * vj[2].y;
-      gsw[2].x = gdv[0].x * rk[0] + gdv[1].x * rk[1] + gdv[2].x * rk[2];
-      gsw[2].y = gdv[0].y * rk[0] + gdv[1].y * rk[1] + gdv[2].y * rk[2];
-      float gd = 0.0f;
-#pragma unroll
-      for (int p = 0; p < 3; ++p) {
-        gs[p].x += gsw[p].x * wf[p].x;
-        gs[p].y += gsw[p].y * wf[p].y;
-        gd += gsw[p].x * sj[p].x * wd[p].x + gsw[p].y * sj[p].y * wd[p].y;
-      }
-      const float2 sw2 = make_float2(sj[1].x * wf[1].x, sj[1].y * wf[1].y);
-      const float2 sw3 = make_float2(sj[2].x * wf[2].x, sj[2].y * wf[2].y);
-      float gr[3];
-#pragma unroll
-      for (int k = 0; k < 3; ++k) {
-        gv[k].x += gdv[k].x * sw2.x;
-        gv[k].y += gdv[k].y * sw2.y;
-        gr[k] = gdv[k].x * sw3.x + gdv[k].y * sw3.y;
-      }
-      gd = wave_sum(gd);
-#pragma unroll
-      for (int k = 0; k < 3; ++k) gr[k] = wave_sum(gr[k]);
-      if (lane == 0) {
-        if (a.accumulate) {
-          a.g_d[r] += gd;
-#pragma unroll
-          for (int k = 0; k < 3; ++k) a.g_rij[static_cast<int64_t>(r) * 3 + k] += gr[k];
-        } else {
-          a.g_d[r] = gd;
-#pragma unroll
-          for (int k = 0; k < 3; ++k) a.g_rij[static_cast<int64_t>(r) * 3 + k] = gr[k];
-        }
-      }
     }
 #pragma unroll
-    for (int p = 0; p < 3; ++p)
-      *reinterpret_cast<float2*>(a.g_s + static_cast<int64_t>(j) * 3 * F + p * F + 2 * lane) = gs[p];
+    for (int p = 0; p < 3; ++p) a.g_s[static_cast<int64_t>(j) * 3 * F + p * F + f0] = gs[p];
     if (a.g_v) {
 #pragma unroll
       for (int k = 0; k < 3; ++k) {
-        const float2 up = *reinterpret_cast<const float2*>(a.g_dv + (static_cast<int64_t>(j) * 3 + k) * F + 2 * lane);
-        *reinterpret_cast<float2*>(a.g_v + (static_cast<int64_t>(j) * 3 + k) * F + 2 * lane) =
-            make_float2(up.x + gv[k].x, up.y + gv[k].y);
+        const int64_t at = (static_cast<int64_t>(j) * 3 + k) * F + f0;
+        a.g_v[at] = a.g_dv[at] + gv[k];
       }
     }
   }
@@ -489,15 +506,22 @@ __global__ void painn_update_pre_bwd_kernel(const float* __restrict__ gz2, const
 
 // ---------------------------------------------------------------------------------------------------- geometry, backward
 // dE/dx_n = sum_{e: recv = n} t_e - sum_{e: send = n} t_e,  t_e = g_d r_ij + (g_r - (g_r . r_ij) r_ij) / d
-// (d = |x_i - x_j|, r_ij = (x_i - x_j) / d with divide_no_nan: no contribution at d = 0).  One thread per node, both
-// CSRs walked in order: deterministic.  scale = -1 returns the physical force directly.
-__global__ void painn_geometry_bwd_kernel(const float* __restrict__ g_d, const float* __restrict__ g_rij,
-                                          const float* __restrict__ rij, const float* __restrict__ d,
-                                          const int32_t* __restrict__ ptr0, const int32_t* __restrict__ perm0,
-                                          const int32_t* __restrict__ ptr1, const int32_t* __restrict__ perm1, int64_t N,
-                                          int64_t M, float scale, float* __restrict__ gx) {
-  const int64_t stride = static_cast<int64_t>(gridDim.x) * blockDim.x;
-  for (int64_t n = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x; n < N; n += stride) {
+// (d = |x_i - x_j|, r_ij = (x_i - x_j) / d with divide_no_nan: no contribution at d = 0); g_d / g_rij arrive as `slices`
+// partial buffers (the two feature halves of the message reverse kernel) that are added here.  One wave per node, lanes
+// stride the node's receiver-side and sender-side edge lists, fixed-shape wave reduction: deterministic.  scale = -1
+// returns the physical force directly.
+__global__ __launch_bounds__(256) void painn_geometry_bwd_kernel(const float* __restrict__ g_d,
+                                                                 const float* __restrict__ g_rij, int slices,
+                                                                 const float* __restrict__ rij,
+                                                                 const float* __restrict__ d,
+                                                                 const int32_t* __restrict__ ptr0,
+                                                                 const int32_t* __restrict__ perm0,
+                                                                 const int32_t* __restrict__ ptr1,
+                                                                 const int32_t* __restrict__ perm1, int64_t N, int64_t M,
+                                                                 float scale, float* __restrict__ gx) {
+  const int lane = threadIdx.x & 63;
+  const int64_t nwaves = (static_cast<int64_t>(gridDim.x) * blockDim.x) >> 6;
+  for (int64_t n = (static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x) >> 6; n < N; n += nwaves) {
     float acc[3] = {0.0f, 0.0f, 0.0f};
     for (int side = 0; side < 2; ++side) {
       const int32_t* ptr = side == 0 ? ptr0 : ptr1;
@@ -506,23 +530,32 @@ __global__ void painn_geometry_bwd_kernel(const float* __restrict__ g_d, const f
       int lo = ptr[n], hi = ptr[n + 1];
       lo = lo < 0 ? 0 : lo;
       hi = hi > M ? static_cast<int>(M) : hi;
-      for (int e = lo; e < hi; ++e) {
+      for (int e = lo + lane; e < hi; e += 64) {
         const int64_t r = perm ? perm[e] : e;
         const float dist = d[r];
         if (dist == 0.0f) continue;
         const float r0 = rij[r * 3], r1 = rij[r * 3 + 1], r2 = rij[r * 3 + 2];
-        const float q0 = g_rij[r * 3], q1 = g_rij[r * 3 + 1], q2 = g_rij[r * 3 + 2];
+        float gd = 0.0f, q0 = 0.0f, q1 = 0.0f, q2 = 0.0f;
+        for (int sl = 0; sl < slices; ++sl) {
+          gd += g_d[sl * M + r];
+          q0 += g_rij[(sl * M + r) * 3];
+          q1 += g_rij[(sl * M + r) * 3 + 1];
+          q2 += g_rij[(sl * M + r) * 3 + 2];
+        }
         const float dot = q0 * r0 + q1 * r1 + q2 * r2;
         const float inv = 1.0f / dist;
-        const float gd = g_d[r];
         acc[0] += sign * (gd * r0 + (q0 - dot * r0) * inv);
         acc[1] += sign * (gd * r1 + (q1 - dot * r1) * inv);
         acc[2] += sign * (gd * r2 + (q2 - dot * r2) * inv);
       }
     }
-    gx[n * 3 + 0] = scale * acc[0];
-    gx[n * 3 + 1] = scale * acc[1];
-    gx[n * 3 + 2] = scale * acc[2];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) acc[k] = wave_sum(acc[k]);
+    if (lane == 0) {
+      gx[n * 3 + 0] = scale * acc[0];
+      gx[n * 3 + 1] = scale * acc[1];
+      gx[n * 3 + 2] = scale * acc[2];
+    }
   }
 }
 
@@ -546,15 +579,7 @@ int mp_painn_stage0_f32(const float* numbers, int64_t N, const float* emb, int v
   MP_REQUIRE(cos_cutoff <= 0.0f || env != nullptr, "mp_painn_stage0_f32: envelope requested without a buffer");
   PainnNodeInit ni{numbers, emb, vocab, N, v_init, z0, v0};
   mp_prep::EdgePrepArgs p{idx, M, node_splits, edge_splits, G, N, xyz, recv, send, dist, flags};
-  const int pe = envelope_exponent + 1;
-  PainnEdgeExtra ex{};
-  ex.rij = rij; ex.freq = frequencies; ex.B = num_radial; ex.inv_cutoff = 1.0f / bessel_cutoff; ex.p = pe;
-  ex.a = static_cast<float>(-(pe + 1) * (pe + 2) / 2.0);
-  ex.b = static_cast<float>(pe * (pe + 2));
-  ex.c = static_cast<float>(-pe * (pe + 1) / 2.0);
-  ex.rbf = rbf; ex.rbfd = rbfd; ex.cos_cutoff = cos_cutoff;
-  ex.env = cos_cutoff > 0.0f ? env : nullptr;
-  ex.envd = cos_cutoff > 0.0f ? envd : nullptr;
+  PainnEdgeExtra ex{rij};
   const int node_blocks = static_cast<int>(mp::grid_for(N * F));
   const int edge_blocks = M > 0 ? static_cast<int>(mp::grid_for(M)) : 0;
   hipStream_t s = mp::as_stream(stream);
@@ -562,6 +587,20 @@ int mp_painn_stage0_f32(const float* numbers, int64_t N, const float* emb, int v
     painn_stage0_kernel<true><<<node_blocks + edge_blocks, 256, 0, s>>>(ni, p, ex, node_blocks);
   else
     painn_stage0_kernel<false><<<node_blocks + edge_blocks, 256, 0, s>>>(ni, p, ex, node_blocks);
+  if (M > 0) {
+    const int pe = envelope_exponent + 1;
+    PainnBasisArgs q{};
+    q.dist = dist; q.M = M; q.freq = frequencies; q.B = num_radial; q.inv_cutoff = 1.0f / bessel_cutoff; q.p = pe;
+    q.a = static_cast<float>(-(pe + 1) * (pe + 2) / 2.0);
+    q.b = static_cast<float>(pe * (pe + 2));
+    q.c = static_cast<float>(-pe * (pe + 1) / 2.0);
+    q.rbf = rbf; q.rbfd = rbfd; q.cos_cutoff = cos_cutoff;
+    q.env = cos_cutoff > 0.0f ? env : nullptr;
+    q.envd = cos_cutoff > 0.0f ? envd : nullptr;
+    const int rc = mp::check_launch("mp_painn_stage0_f32");
+    if (rc != MP_OK) return rc;
+    painn_basis_kernel<<<mp::grid_for(M * num_radial), 256, 0, s>>>(q);
+  }
   return mp::check_launch("mp_painn_stage0_f32");
 }
 
@@ -574,8 +613,8 @@ int mp_painn_message_f32(const float* s, const float* v, int64_t N, const float*
   MP_REQUIRE(M < (int64_t{1} << 31) && N < (int64_t{1} << 31), "mp_painn_message_f32: sizes must fit int32");
   MP_REQUIRE(dv != v, "mp_painn_message_f32: dv must not alias v (other waves still gather v)");
   PainnMsgArgs a{s, v, rbf, env, rij, Ww, bw, ptr, perm, send, z_in, ds, dv, N, M, B};
-  int64_t blocks = mp::ceil_div(N, 4);
-  if (blocks > 2048) blocks = 2048;
+  int64_t blocks = mp::ceil_div(2 * N, 4);   // two waves (feature halves) per node, four waves per workgroup
+  if (blocks > 4096) blocks = 4096;
   hipStream_t st = mp::as_stream(stream);
   if (B == 20) painn_message_kernel<20><<<static_cast<unsigned>(blocks), 256, 0, st>>>(a);
   else painn_message_kernel<0><<<static_cast<unsigned>(blocks), 256, 0, st>>>(a);
@@ -595,8 +634,8 @@ int mp_painn_message_bwd_f32(const float* s, const float* v, int64_t N, const fl
   MP_REQUIRE(g_v != g_dv, "mp_painn_message_bwd_f32: g_v must not alias g_dv (other waves still gather g_dv)");
   PainnMsgBwdArgs a{s, v, rbf, rbfd, env, envd, rij, Ww, bw, ptr1, perm1, recv, g_ds, g_dv, g_s, g_v, g_d, g_rij,
                     accumulate, N, M, B};
-  int64_t blocks = mp::ceil_div(N, 4);
-  if (blocks > 2048) blocks = 2048;
+  int64_t blocks = mp::ceil_div(2 * N, 4);   // two waves (feature halves) per node
+  if (blocks > 4096) blocks = 4096;
   hipStream_t st = mp::as_stream(stream);
   if (B == 20) painn_message_bwd_kernel<20><<<static_cast<unsigned>(blocks), 256, 0, st>>>(a);
   else painn_message_bwd_kernel<0><<<static_cast<unsigned>(blocks), 256, 0, st>>>(a);
@@ -641,14 +680,15 @@ int mp_painn_update_pre_bwd_f32(const float* g_z2, const float* g_v2, const floa
   return mp::check_launch("mp_painn_update_pre_bwd_f32");
 }
 
-int mp_edge_geometry_bwd_f32(const float* g_d, const float* g_rij, const float* rij, const float* dist,
+int mp_edge_geometry_bwd_f32(const float* g_d, const float* g_rij, int slices, const float* rij, const float* dist,
                              const int32_t* ptr0, const int32_t* perm0, const int32_t* ptr1, const int32_t* perm1,
                              int64_t N, int64_t M, float scale, float* g_xyz, mpStream_t stream) {
-  MP_REQUIRE(N >= 0 && M >= 0, "mp_edge_geometry_bwd_f32: bad sizes");
+  MP_REQUIRE(N >= 0 && M >= 0 && slices >= 1, "mp_edge_geometry_bwd_f32: bad sizes");
   if (N == 0) return MP_OK;
   MP_REQUIRE(ptr0 && ptr1 && g_xyz && (M == 0 || (g_d && g_rij && rij && dist)), "mp_edge_geometry_bwd_f32: null pointer");
-  painn_geometry_bwd_kernel<<<mp::grid_for(N, 64), 64, 0, mp::as_stream(stream)>>>(g_d, g_rij, rij, dist, ptr0, perm0,
-                                                                                   ptr1, perm1, N, M, scale, g_xyz);
+  painn_geometry_bwd_kernel<<<mp::grid_for(N * 64), 256, 0, mp::as_stream(stream)>>>(g_d, g_rij, slices, rij, dist, ptr0,
+                                                                                     perm0, ptr1, perm1, N, M, scale,
+                                                                                     g_xyz);
   return mp::check_launch("mp_edge_geometry_bwd_f32");
 }
 

@@ -238,14 +238,25 @@ class GraphedModel:
         self.model, self.inputs, self.grad = model, inputs, bool(grad)
         self.stream = torch.cuda.Stream()
         self.stream.wait_stream(torch.cuda.current_stream())
-        with torch.cuda.stream(self.stream), torch.set_grad_enabled(self.grad):
-            for _ in range(3):
-                model(inputs)
-        torch.cuda.synchronize()
-        self.graph = torch.cuda.CUDAGraph()
-        with torch.set_grad_enabled(self.grad), torch.cuda.graph(self.graph, stream=self.stream):
-            self.output = model(inputs)
-        torch.cuda.synchronize()
+        # Models with a fused route replay their own HIP graph per bound batch; launching that graph into a capturing
+        # stream would nest graphs, so for the capture the route issues its kernels directly (they land in THIS graph).
+        routes = [r for r in (getattr(model, "fused", None), getattr(getattr(model, "energy_model", None), "fused", None))
+                  if r is not None and hasattr(r, "mode")]
+        saved = [r.mode for r in routes]
+        for r in routes:
+            r.mode = "eager"
+        try:
+            with torch.cuda.stream(self.stream), torch.set_grad_enabled(self.grad):
+                for _ in range(3):
+                    model(inputs)
+            torch.cuda.synchronize()
+            self.graph = torch.cuda.CUDAGraph()
+            with torch.set_grad_enabled(self.grad), torch.cuda.graph(self.graph, stream=self.stream):
+                self.output = model(inputs)
+            torch.cuda.synchronize()
+        finally:
+            for r, mode in zip(routes, saved):
+                r.mode = mode
 
     def __call__(self):
         self.graph.replay()

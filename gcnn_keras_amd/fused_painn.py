@@ -122,13 +122,15 @@ class FusedPainn:
         self.envd = e(mm) if (self.cos_cutoff > 0 and self.grad) else None
         self.z0, self.v0 = e(n, 128), e(n, 3, 128)
         nblk = self.depth if self.grad else 1   # the reverse pass needs every block's intermediates
-        self.blk = [{"h1": e(n, 128), "s": e(n, 384), "zp": e(n, 128), "vp": e(n, 3, 128), "uv": e(3 * n, 256),
-                     "c": e(n, 256), "prod": e(n, 128), "h2": e(n, 128), "a": e(n, 384)} for _ in range(nblk)]
+        self.blk = [{"h1": e(n, 128), "a1": e(n, 128), "s": e(n, 384), "zp": e(n, 128), "vp": e(n, 3, 128),
+                     "uv": e(3 * n, 256), "c": e(n, 256), "prod": e(n, 128), "h2": e(n, 128), "a2": e(n, 128),
+                     "a": e(n, 384)} for _ in range(nblk)]
         nzv = self.depth if self.grad else 2    # block outputs: all of them (v_in of the next block is saved) or ping-pong
         self.zs = [e(n, 128) for _ in range(nzv)]
         self.vs = [e(n, 3, 128) for _ in range(nzv)]
         self.pooled = e(g, 128)
         self.pre_out = [e(g, u) for u in self.out_units]
+        self.post_out = [e(g, u) for u in self.out_units]
         splits = node.row_splits_host()
         rows = g
         while rows > 0 and splits[rows] == splits[rows - 1]:
@@ -143,15 +145,16 @@ class FusedPainn:
             self.g_a, self.g_prod, self.g_a2, self.g_c = e(n, 384), e(n, 128), e(n, 128), e(n, 256)
             self.g_zp, self.g_uv, self.g_vp = e(n, 128), e(3 * n, 256), e(n, 3, 128)
             self.g_s, self.g_a1 = e(n, 384), e(n, 128)
-            self.g_d, self.g_rij = e(mm), e(mm, 3)
+            self.g_d, self.g_rij = e(2, mm), e(2, mm, 3)   # one slice per feature half of the reverse message kernel
             self.force = e(n, 3)
         self.graphs = {}
 
     # ------------------------------------------------------------------------------------------------ launches
     @staticmethod
-    def _dense(x, rows, k, w, b, u, out, in_mode=0, in_act=0, in_pre=None, addend=None):
-        _ffi.call("mp_dense_ex_f32", _ffi.ptr(x), rows, k, _ffi.ptr(w), _ffi.ptr(b), u, 0, 0.0, in_mode, in_act, 0.0,
-                  _ffi.ptr(in_pre), _ffi.ptr(addend), _ffi.ptr(out), _ffi.stream())
+    def _dense(x, rows, k, w, b, u, out, act=0, out_pre=None, grad_act=0, grad_pre=None, addend=None):
+        """out = act(x W + b) [* grad_act'(grad_pre)] [+ addend]; out_pre additionally keeps x W + b."""
+        _ffi.call("mp_dense_ex_f32", _ffi.ptr(x), rows, k, _ffi.ptr(w), _ffi.ptr(b), u, act, 0.0, 0, grad_act, 0.0,
+                  None, _ffi.ptr(addend), _ffi.ptr(out_pre), _ffi.ptr(grad_pre), _ffi.ptr(out), _ffi.stream())
 
     def _forward(self):
         p, w, n, m = self.p, self.w, self.N, self.M
@@ -168,9 +171,10 @@ class FusedPainn:
             c, u = "conv%d/" % i, "update%d/" % i
             t = self.blk[i if self.grad else 0]
             z_out, v_out = self.zs[i % len(self.zs)], self.vs[i % len(self.vs)]
-            self._dense(z, n, 128, p[c + "dense1/kernel"], p.get(c + "dense1/bias"), 128, t["h1"])
-            self._dense(t["h1"], n, 128, p[c + "phi/kernel"], p.get(c + "phi/bias"), 384, t["s"], in_mode=1,
-                        in_act=self.act_conv)
+            # Dense(act) writes the activation and (for the reverse pass) keeps the pre-activation h1 beside it
+            self._dense(z, n, 128, p[c + "dense1/kernel"], p.get(c + "dense1/bias"), 128, t["a1"], act=self.act_conv,
+                        out_pre=t["h1"] if self.grad else None)
+            self._dense(t["a1"], n, 128, p[c + "phi/kernel"], p.get(c + "phi/bias"), 384, t["s"])
             _ffi.call("mp_painn_message_f32", _ffi.ptr(t["s"]), _ffi.ptr(v), n, _ffi.ptr(self.rbf), self.B,
                       _ffi.ptr(self.env), _ffi.ptr(self.rij), _ffi.ptr(p[c + "w/kernel"]), _ffi.ptr(p.get(c + "w/bias")),
                       _ffi.ptr(self.ptr0), _ffi.ptr(self.perm0), _ffi.ptr(self.send), m, _ffi.ptr(z), _ffi.ptr(t["zp"]),
@@ -178,9 +182,9 @@ class FusedPainn:
             self._dense(t["vp"], 3 * n, 128, w["uv%d" % i], None, 256, t["uv"])
             _ffi.call("mp_painn_update_pre_f32", _ffi.ptr(t["zp"]), _ffi.ptr(t["uv"]), n, _ffi.ptr(t["c"]),
                       _ffi.ptr(t["prod"]), _ffi.stream())
-            self._dense(t["c"], n, 256, p[u + "dense1/kernel"], p.get(u + "dense1/bias"), 128, t["h2"])
-            self._dense(t["h2"], n, 128, p[u + "a/kernel"], p.get(u + "a/bias"), 384, t["a"], in_mode=1,
-                        in_act=self.act_upd)
+            self._dense(t["c"], n, 256, p[u + "dense1/kernel"], p.get(u + "dense1/bias"), 128, t["a2"], act=self.act_upd,
+                        out_pre=t["h2"] if self.grad else None)
+            self._dense(t["a2"], n, 128, p[u + "a/kernel"], p.get(u + "a/bias"), 384, t["a"])
             _ffi.call("mp_painn_update_post_f32", _ffi.ptr(t["zp"]), _ffi.ptr(t["vp"]), _ffi.ptr(t["uv"]),
                       _ffi.ptr(t["prod"]), _ffi.ptr(t["a"]), n, _ffi.ptr(z_out), _ffi.ptr(v_out), _ffi.stream())
             z, v = z_out, v_out
@@ -188,10 +192,12 @@ class FusedPainn:
         _ffi.call("mp_pool_graph_f32", _ffi.MP_SUM, _ffi.ptr(z), _ffi.ptr(node.row_splits), self.G, 128, None,
                   _ffi.ptr(self.pooled), _ffi.stream())
         x, k_in = self.pooled, 128
-        for k, units in enumerate(self.out_units):
+        last = len(self.out_units) - 1
+        for k, units in enumerate(self.out_units):   # act_out[last] is linear: post_out[last] is the energy
             self._dense(x, self.G, k_in, p["output_mlp/%d/kernel" % k], p.get("output_mlp/%d/bias" % k), units,
-                        self.pre_out[k], in_mode=1 if k > 0 else 0, in_act=self.act_out[k - 1] if k > 0 else 0)
-            x, k_in = self.pre_out[k], units
+                        self.post_out[k], act=self.act_out[k],
+                        out_pre=self.pre_out[k] if (self.grad and k < last) else None)
+            x, k_in = self.post_out[k], units
 
     def _backward(self):
         """dE/dx for one energy state: the forward's kernels mirrored, last to first (kgcnn/model/force.py:159-177 computes
@@ -200,10 +206,10 @@ class FusedPainn:
         node = self.inputs[0]
         last = len(self.out_units) - 1
         t, k_in = self.ones, self.out_units[-1]
-        for k in range(last, -1, -1):   # t = dE/d act_k(pre_k) -> dE/d(input of layer k)
+        for k in range(last, -1, -1):   # t = dE/d pre_k -> dE/d pre_{k-1} = (t W_k^T) * act_{k-1}'(pre_{k-1})
             width = 128 if k == 0 else self.out_units[k - 1]
             self._dense(t, self.G, k_in, w["output_mlp/%d/T" % k], None, width, self.g_out[k],
-                        in_mode=2 if k < last else 0, in_act=self.act_out[k], in_pre=self.pre_out[k] if k < last else None)
+                        grad_act=self.act_out[k - 1] if k > 0 else 0, grad_pre=self.pre_out[k - 1] if k > 0 else None)
             t, k_in = self.g_out[k], width
         _ffi.call("mp_repeat_rows_f32", _ffi.ptr(t), _ffi.ptr(node.row_splits), self.G, 128, n, _ffi.ptr(self.gz),
                   _ffi.stream())
@@ -214,9 +220,8 @@ class FusedPainn:
             v_in = self.v0 if i == 0 else self.vs[i - 1]
             _ffi.call("mp_painn_update_post_bwd_f32", _ffi.ptr(self.gz), _ffi.ptr(self.gv), _ffi.ptr(b["uv"]),
                       _ffi.ptr(b["prod"]), _ffi.ptr(b["a"]), n, _ffi.ptr(self.g_a), _ffi.ptr(self.g_prod), _ffi.stream())
-            self._dense(self.g_a, n, 384, w[u + "a/T"], None, 128, self.g_a2)
-            self._dense(self.g_a2, n, 128, w[u + "dense1/T"], None, 256, self.g_c, in_mode=2, in_act=self.act_upd,
-                        in_pre=b["h2"])
+            self._dense(self.g_a, n, 384, w[u + "a/T"], None, 128, self.g_a2, grad_act=self.act_upd, grad_pre=b["h2"])
+            self._dense(self.g_a2, n, 128, w[u + "dense1/T"], None, 256, self.g_c)
             _ffi.call("mp_painn_update_pre_bwd_f32", _ffi.ptr(self.gz), _ffi.ptr(self.gv), _ffi.ptr(b["uv"]),
                       _ffi.ptr(b["c"]), _ffi.ptr(b["a"]), _ffi.ptr(self.g_prod), _ffi.ptr(self.g_c), n,
                       _ffi.ptr(self.g_zp), _ffi.ptr(self.g_uv), _ffi.stream())
@@ -228,10 +233,10 @@ class FusedPainn:
                       _ffi.ptr(self.g_s), _ffi.ptr(self.gv) if i > 0 else None, _ffi.ptr(self.g_d), _ffi.ptr(self.g_rij),
                       0 if i == self.depth - 1 else 1, _ffi.stream())
             if i > 0:   # block 0's inputs (embedding, constant v) do not depend on the coordinates
-                self._dense(self.g_s, n, 384, w[c + "phi/T"], None, 128, self.g_a1)
-                self._dense(self.g_a1, n, 128, w[c + "dense1/T"], None, 128, self.gz, in_mode=2, in_act=self.act_conv,
-                            in_pre=b["h1"], addend=self.g_zp)
-        _ffi.call("mp_edge_geometry_bwd_f32", _ffi.ptr(self.g_d), _ffi.ptr(self.g_rij), _ffi.ptr(self.rij),
+                self._dense(self.g_s, n, 384, w[c + "phi/T"], None, 128, self.g_a1, grad_act=self.act_conv,
+                            grad_pre=b["h1"])
+                self._dense(self.g_a1, n, 128, w[c + "dense1/T"], None, 128, self.gz, addend=self.g_zp)
+        _ffi.call("mp_edge_geometry_bwd_f32", _ffi.ptr(self.g_d), _ffi.ptr(self.g_rij), 2, _ffi.ptr(self.rij),
                   _ffi.ptr(self.dist), _ffi.ptr(self.ptr0), _ffi.ptr(self.perm0), _ffi.ptr(self.ptr1),
                   _ffi.ptr(self.perm1), n, m, -1.0, _ffi.ptr(self.force), _ffi.stream())
 
@@ -263,7 +268,7 @@ class FusedPainn:
             _ffi.call("mp_graph_launch", graph, _ffi.stream())
         else:
             self._launch(with_forces)
-        eng = self.pre_out[-1]
+        eng = self.post_out[-1]
         return (eng if self.out_rows == self.G else eng[:self.out_rows]), (self.force if with_forces else None)
 
     def check_flags(self):

@@ -154,10 +154,12 @@ int mp_dense_f32(const float* x, int64_t R, int64_t K, const float* W, const flo
  * kgcnn/layers/conv/painn_conv.py:98-99, 206-207; EnergyForceModel's tape, kgcnn/model/force.py:159-177):
  * in_mode 0: as mp_dense_f32; 1: x := in_act(x) while staging (x is a saved pre-activation); 2: x := x * in_act'(in_pre)
  * (in_pre (R,K): the reverse pass through an activation, fused into the GEMM with the transposed kernel).
- * addend (R,U) nullable, may alias out: out = act(x W + b) + addend. */
+ * Epilogue, in this order: out_pre (R,U) nullable receives the pre-activation x W + b; the result act(x W + b) is
+ * multiplied by in_act'(grad_pre) if grad_pre (R,U) is given (the activation derivative applied where the upstream
+ * gradient is produced); addend (R,U) nullable, may alias out, is added last. */
 int mp_dense_ex_f32(const float* x, int64_t R, int64_t K, const float* W, const float* b, int64_t U, int act,
                     float act_alpha, int in_mode, int in_act, float in_alpha, const float* in_pre, const float* addend,
-                    float* out, mpStream_t stream);
+                    float* out_pre, const float* grad_pre, float* out, mpStream_t stream);
 
 int mp_activation_f32(int act, float act_alpha, const float* x, int64_t n, float* out, mpStream_t stream);
 int mp_softmax_rows_f32(const float* x, int64_t R, int64_t C, float* out, mpStream_t stream);
@@ -279,7 +281,8 @@ int mp_painn_message_f32(const float* s, const float* v, int64_t N, const float*
 /* Reverse pass of the message block (painn_conv.py:99-113) for forces: sender-parallel over the CSR of column 1
  * (ptr1 / perm1).  Given g_ds (N,F) and g_dv (N,3,F): g_s (N,3F) = dE/ds, g_v (N,3,F) = g_dv + dE/dv through the
  * messages (nullable), and per edge dE/dd (through the filter: rbfd = d rbf / d d, envelope by the product rule) and
- * dE/dr_ij, written (accumulate = 0) or added (accumulate = 1, later blocks) to g_d (M), g_rij (M,3). */
+ * dE/dr_ij, written (accumulate = 0) or added (accumulate = 1, later blocks) to g_d (2,M), g_rij (2,M,3): one slice per
+ * half of the feature axis (two waves serve a sender), summed by mp_edge_geometry_bwd_f32 (slices = 2). */
 int mp_painn_message_bwd_f32(const float* s, const float* v, int64_t N, const float* rbf, const float* rbfd, int B,
                              const float* env, const float* envd, const float* rij, const float* Ww, const float* bw,
                              const int32_t* ptr1, const int32_t* perm1, const int32_t* recv, int64_t M, const float* g_ds,
@@ -299,9 +302,10 @@ int mp_painn_update_pre_bwd_f32(const float* g_z2, const float* g_v2, const floa
                                 mpStream_t stream);
 /* Reverse of NodePosition -> EdgeDirectionNormalized / NodeDistanceEuclidean (PAiNN.py:116-118; Schnet.py:116-117 with
  * g_rij = 0): g_xyz[n] = scale * (sum_{recv(e)=n} t_e - sum_{send(e)=n} t_e), t_e = g_d r_ij + (g_rij - (g_rij.r_ij) r_ij)/d,
+ * g_d (slices,M) and g_rij (slices,M,3) being partial sums that are added first,
  * over the receiver CSR (ptr0/perm0) and the sender CSR (ptr1/perm1); scale = -1 yields the physical force
  * (kgcnn/model/force.py:188-189). */
-int mp_edge_geometry_bwd_f32(const float* g_d, const float* g_rij, const float* rij, const float* dist,
+int mp_edge_geometry_bwd_f32(const float* g_d, const float* g_rij, int slices, const float* rij, const float* dist,
                              const int32_t* ptr0, const int32_t* perm0, const int32_t* ptr1, const int32_t* perm1,
                              int64_t N, int64_t M, float scale, float* g_xyz, mpStream_t stream);
 

@@ -1,0 +1,32 @@
+"""Kernel statistics of a rocprofv3 run (ROCm 7.2 writes an SQLite `*_results.db`): per kernel calls, average / min / max
+duration and share of the total kernel time, as the tracked CSV summaries under profiles/.
+
+    python scripts/rocprof_db_stats.py gpurun_out/prof_x/x_results.db profiles/r02_x_kernel_stats.csv "title"
+"""
+import sqlite3
+import sys
+
+
+def short(name):
+    name = name.replace("(anonymous namespace)::", "").replace("void ", "")
+    cut = name.find("(")
+    return (name if cut < 0 else name[:cut])[:70]
+
+
+def main():
+    db_path, out_path = sys.argv[1], sys.argv[2]
+    title = sys.argv[3] if len(sys.argv) > 3 else db_path
+    cur = sqlite3.connect(db_path).cursor()
+    rows = cur.execute("select name, count(*), avg(end - start), min(end - start), max(end - start), sum(end - start) "
+                       "from kernels group by name order by 6 desc").fetchall()
+    total = sum(r[5] for r in rows) or 1
+    with open(out_path, "w") as f:
+        f.write("# %s\n# source: rocprofv3 --kernel-trace --stats (%s), MI355X\n" % (title, db_path))
+        f.write("kernel,calls,avg_us,min_us,max_us,percent\n")
+        for name, calls, avg, mn, mx, tot in rows:
+            f.write("%s,%d,%.2f,%.2f,%.2f,%.2f\n" % (short(name), calls, avg / 1e3, mn / 1e3, mx / 1e3, 100.0 * tot / total))
+    print(open(out_path).read())
+
+
+if __name__ == "__main__":
+    main()
