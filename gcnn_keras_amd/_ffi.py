@@ -54,6 +54,8 @@ _SIGNATURES = {
     "mp_scatter_relational_f32": [c_int, P, c_int64, c_int64, P, P, c_int64, c_int64, P, P],
     "mp_dense_f32": [P, c_int64, c_int64, P, P, c_int64, c_int, c_float, P, P],
     "mp_dense_ex_f32": [P, c_int64, c_int64, P, P, c_int64, c_int, c_float, c_int, c_int, c_float, P, P, P, P, P, P],
+    "mp_dense_splitk_workspace_bytes": [c_int64, c_int64, c_int, P],
+    "mp_dense_splitk_f32": [P, c_int64, c_int64, P, P, c_int64, c_int, c_float, c_int, P, c_size_t, P, P],
     "mp_activation_f32": [c_int, c_float, P, c_int64, P, P],
     "mp_softmax_rows_f32": [P, c_int64, c_int64, P, P],
     "mp_binary_f32": [c_int, P, P, P, P, c_int64, c_int64, c_int64, P, P],
@@ -140,15 +142,23 @@ def declared_symbols():
 
 
 def lib():
-    """Load libmpengine.so once.  Raises if it was not built (run ``python -c 'import __graft_entry__ as g; g.build()'``)."""
+    """Load libmpengine.so once.  Raises if it was not built (run ``python -c 'import __graft_entry__ as g; g.build()'``).
+    ``MPENGINE_LIB`` names another build of the same ABI - used by ``make -C gcnn_keras_amd/csrc asan``, whose
+    host-only AddressSanitizer build exports the host packer and runtime entry points only (missing kernels are then
+    simply not bound; calling one raises AttributeError)."""
     global _lib
     if _lib is None:
-        if not os.path.exists(LIB_PATH):
+        path = os.environ.get("MPENGINE_LIB") or LIB_PATH
+        if not os.path.exists(path):
             raise EngineError("libmpengine.so not found at %s - build it with __graft_entry__.build() "
-                              "(there is no CPU fallback)" % LIB_PATH)
-        handle = ctypes.CDLL(LIB_PATH)
+                              "(there is no CPU fallback)" % path)
+        handle = ctypes.CDLL(path)
         for name, argtypes in _SIGNATURES.items():
-            fn = getattr(handle, name)
+            fn = getattr(handle, name, None)
+            if fn is None:
+                if path == LIB_PATH:
+                    raise EngineError("libmpengine.so lacks %s - rebuild it (__graft_entry__.build())" % name)
+                continue
             fn.argtypes = argtypes
             fn.restype = _RESTYPES.get(name, c_int)
         _lib = handle
@@ -194,9 +204,48 @@ def launch_count():
     return _launches[0]
 
 
+_roctx = None
+
+
+def enable_roctx(on=True):
+    """Bracket every engine call in a roctx range named after the entry point (``rocprofv3 --marker-trace`` then shows
+    which C-ABI call a kernel belongs to).  Also switched on by ``MPENGINE_ROCTX=1``.  Off by default: two extra
+    library calls per launch."""
+    global _roctx
+    if not on:
+        _roctx = None
+        return
+    for cand in ("libroctx64.so", "/opt/rocm/lib/libroctx64.so", "librocprofiler-sdk-roctx.so",
+                 "/opt/rocm/lib/librocprofiler-sdk-roctx.so"):
+        try:
+            h = ctypes.CDLL(cand)
+            h.roctxRangePushA.argtypes = [c_char_p]
+            h.roctxRangePushA.restype = c_int
+            h.roctxRangePop.restype = c_int
+            _roctx = h
+            return
+        except (OSError, AttributeError):
+            continue
+    raise EngineError("no roctx library found under /opt/rocm/lib")
+
+
 def call(name, *args):
     _launches[0] += 1
+    if _roctx is not None:
+        _roctx.roctxRangePushA(name.encode())
+        try:
+            check(getattr(lib(), name)(*args))
+        finally:
+            _roctx.roctxRangePop()
+        return
     check(getattr(lib(), name)(*args))
+
+
+if os.environ.get("MPENGINE_ROCTX") == "1":
+    try:
+        enable_roctx()
+    except EngineError:
+        pass
 
 
 def activation_code(name):

@@ -34,6 +34,8 @@ struct DenseExtra {
   float* out_pre;        // (R, U) or null: also store the pre-activation x W + b (kept for the reverse pass)
   const float* grad_pre; // (R, U) or null: multiply the result by in_act'(grad_pre) (reverse pass through an activation
                          // fused into the epilogue of the GEMM that produces the upstream gradient)
+  float* partial;        // split-K: (gridDim.z, R, U) raw partial products, reduced by dense_splitk_reduce_kernel
+  int64_t kchunk;        // split-K: k range of one z-slice (a multiple of BK)
 };
 
 // VEC: K % 4 == 0, U % 4 == 0 and 16-B aligned operands: both tiles are fetched with 16-B loads (a quarter of the load
@@ -42,10 +44,13 @@ struct DenseExtra {
 // covers their latency - not where they are loaded (measured on the PaiNN chains: 21 -> ~9 us per (1344,128)x(128,384)
 // GEMM; applied at the load, the activation's first use of the data stalls the wave in front of its MFMAs).
 template <int IN_MODE, bool VEC>
-__global__ __launch_bounds__(256) void dense_mfma_kernel(const float* __restrict__ x, int64_t R, int64_t K,
+__global__ __launch_bounds__(256) void dense_mfma_kernel(const float* __restrict__ x, int64_t R, int64_t Kfull,
                                                          const float* __restrict__ W, const float* __restrict__ b,
                                                          int64_t U, int act, float alpha, float* __restrict__ out,
                                                          DenseExtra ex) {
+  const int64_t xld = Kfull;   // row stride of x (and of in_pre)
+  const int64_t K = (ex.partial && (static_cast<int64_t>(blockIdx.z) + 1) * ex.kchunk < Kfull)
+                        ? (static_cast<int64_t>(blockIdx.z) + 1) * ex.kchunk : Kfull;   // end of this workgroup's k range
   __shared__ __align__(16) float As[BM * A_LD];
   __shared__ __align__(16) float Bs[BK * BN];
 
@@ -72,9 +77,9 @@ __global__ __launch_bounds__(256) void dense_mfma_kernel(const float* __restrict
         const int ar = idx / (BK / 4), ac = (idx % (BK / 4)) * 4;
         const int64_t gr = row0 + ar, gk = k0 + ac;
         const bool ok = gr < R && gk < K;
-        ra4[i] = ok ? *reinterpret_cast<const float4*>(x + gr * K + gk) : make_float4(0.f, 0.f, 0.f, 0.f);
+        ra4[i] = ok ? *reinterpret_cast<const float4*>(x + gr * xld + gk) : make_float4(0.f, 0.f, 0.f, 0.f);
         if constexpr (IN_MODE == 2)
-          rp4[i] = ok ? *reinterpret_cast<const float4*>(ex.in_pre + gr * K + gk) : make_float4(0.f, 0.f, 0.f, 0.f);
+          rp4[i] = ok ? *reinterpret_cast<const float4*>(ex.in_pre + gr * xld + gk) : make_float4(0.f, 0.f, 0.f, 0.f);
         const int br = idx / (BN / 4), bc = (idx % (BN / 4)) * 4;
         const int64_t gk2 = k0 + br, gc = col0 + bc;
         rb4[i] = (gk2 < K && gc < U) ? *reinterpret_cast<const float4*>(W + gk2 * U + gc) : make_float4(0.f, 0.f, 0.f, 0.f);
@@ -86,8 +91,8 @@ __global__ __launch_bounds__(256) void dense_mfma_kernel(const float* __restrict
         const int ar = idx / BK, ac = idx % BK;
         const int64_t gr = row0 + ar, gk = k0 + ac;
         const bool ok = gr < R && gk < K;
-        ra[i] = ok ? x[gr * K + gk] : 0.0f;
-        if constexpr (IN_MODE == 2) rp[i] = ok ? ex.in_pre[gr * K + gk] : 0.0f;
+        ra[i] = ok ? x[gr * xld + gk] : 0.0f;
+        if constexpr (IN_MODE == 2) rp[i] = ok ? ex.in_pre[gr * xld + gk] : 0.0f;
         const int br = idx / BN, bc = idx % BN;
         const int64_t gk2 = k0 + br, gc = col0 + bc;
         rb[i] = (gk2 < K && gc < U) ? W[gk2 * U + gc] : 0.0f;
@@ -126,13 +131,16 @@ __global__ __launch_bounds__(256) void dense_mfma_kernel(const float* __restrict
     }
   };
 
-  const int64_t ktiles = (K + BK - 1) / BK;
-  load_tile(0);
+  // split-K (few output tiles, long K: GCN's (2708,1433)x(1433,64) has 43 tiles for 256 CUs): blockIdx.z owns the k range
+  // [kbeg, K) - the aliased K below is that slice's end - and writes raw partial sums
+  const int64_t kbeg = ex.partial ? static_cast<int64_t>(blockIdx.z) * ex.kchunk : 0;
+  const int64_t ktiles = (K - kbeg + BK - 1) / BK;
+  load_tile(kbeg);
   for (int64_t t = 0; t < ktiles; ++t) {
-    store_tile(t * BK);
+    store_tile(kbeg + t * BK);
     __syncthreads();
-    if (t + 1 < ktiles) load_tile((t + 1) * BK);
-    const int64_t left = K - t * BK;
+    if (t + 1 < ktiles) load_tile(kbeg + (t + 1) * BK);
+    const int64_t left = K - kbeg - t * BK;
     const int steps = left >= BK ? BK / 2 : static_cast<int>((left + 1) / 2);   // k pairs that hold data
     const float* a_ptr = As + (wr * 32 + (lane & 31)) * A_LD + (lane >> 5);
     const float* b_ptr = Bs + (lane >> 5) * BN + wc * 32 + (lane & 31);
@@ -148,6 +156,17 @@ __global__ __launch_bounds__(256) void dense_mfma_kernel(const float* __restrict
   }
 
   const int64_t col = col0 + wc * 32 + (lane & 31);
+  if (ex.partial) {
+    if (col < U) {
+      float* dst = ex.partial + static_cast<int64_t>(blockIdx.z) * R * U;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int64_t row = row0 + wr * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+        if (row < R) dst[row * U + col] = acc[r];
+      }
+    }
+    return;
+  }
   if (col < U) {
     const float bias = b ? b[col] : 0.0f;
 #pragma unroll
@@ -162,6 +181,18 @@ __global__ __launch_bounds__(256) void dense_mfma_kernel(const float* __restrict
         out[row * U + col] = v;
       }
     }
+  }
+}
+
+// out = act(sum_z partial[z] + b): the slices are added in z order (fixed), so the result does not depend on scheduling
+__global__ void dense_splitk_reduce_kernel(const float* __restrict__ partial, int splits, int64_t R, int64_t U,
+                                           const float* __restrict__ b, int act, float alpha, float* __restrict__ out) {
+  const int64_t total = R * U;
+  const int64_t stride = static_cast<int64_t>(gridDim.x) * blockDim.x;
+  for (int64_t t = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x; t < total; t += stride) {
+    float s = 0.0f;
+    for (int z = 0; z < splits; ++z) s += partial[z * total + t];
+    out[t] = mp_apply_act(act, alpha, s + (b ? b[t % U] : 0.0f));
   }
 }
 
@@ -256,7 +287,7 @@ int mp_dense_f32(const float* x, int64_t R, int64_t K, const float* W, const flo
   MP_REQUIRE(gx <= 65535 && gy < (int64_t{1} << 31), "mp_dense_f32: grid too large");
   dim3 grid(static_cast<unsigned>(gy), static_cast<unsigned>(gx));
   launch_dense<0>(grid, mp::as_stream(stream), x, R, K, W, b, U, act, act_alpha, out,
-                  DenseExtra{0, 0.0f, nullptr, nullptr, nullptr, nullptr});
+                  DenseExtra{0, 0.0f, nullptr, nullptr, nullptr, nullptr, nullptr, 0});
   return mp::check_launch("mp_dense_f32");
 }
 
@@ -273,12 +304,42 @@ int mp_dense_ex_f32(const float* x, int64_t R, int64_t K, const float* W, const 
   const int64_t gy = mp::ceil_div(R, BM), gx = mp::ceil_div(U, BN);
   MP_REQUIRE(gx <= 65535 && gy < (int64_t{1} << 31), "mp_dense_ex_f32: grid too large");
   dim3 grid(static_cast<unsigned>(gy), static_cast<unsigned>(gx));
-  const DenseExtra ex{in_act, in_alpha, in_pre, addend, out_pre, grad_pre};
+  const DenseExtra ex{in_act, in_alpha, in_pre, addend, out_pre, grad_pre, nullptr, 0};
   hipStream_t s = mp::as_stream(stream);
   if (in_mode == 0) launch_dense<0>(grid, s, x, R, K, W, b, U, act, act_alpha, out, ex);
   else if (in_mode == 1) launch_dense<1>(grid, s, x, R, K, W, b, U, act, act_alpha, out, ex);
   else launch_dense<2>(grid, s, x, R, K, W, b, U, act, act_alpha, out, ex);
   return mp::check_launch("mp_dense_ex_f32");
+}
+
+int mp_dense_splitk_workspace_bytes(int64_t R, int64_t U, int splits, size_t* bytes_out_host) {
+  MP_REQUIRE(R >= 0 && U >= 1 && splits >= 1 && bytes_out_host, "mp_dense_splitk_workspace_bytes: bad arguments");
+  *bytes_out_host = sizeof(float) * static_cast<size_t>(R) * static_cast<size_t>(U) * static_cast<size_t>(splits);
+  return MP_OK;
+}
+
+int mp_dense_splitk_f32(const float* x, int64_t R, int64_t K, const float* W, const float* b, int64_t U, int act,
+                        float act_alpha, int splits, void* ws, size_t ws_bytes, float* out, mpStream_t stream) {
+  MP_REQUIRE(R >= 0 && K >= 1 && U >= 1 && splits >= 1 && splits <= 64, "mp_dense_splitk_f32: bad sizes");
+  MP_REQUIRE(act >= MP_ACT_LINEAR && act <= MP_ACT_SOFTPLUS2, "mp_dense_splitk_f32: unknown activation %d", act);
+  if (R == 0) return MP_OK;
+  MP_REQUIRE(x && W && out && ws, "mp_dense_splitk_f32: null pointer");
+  // k range of a slice: a multiple of the k tile; trailing slices that would be empty are dropped
+  int64_t kchunk = mp::ceil_div(mp::ceil_div(K, splits), BK) * BK;
+  const int used = static_cast<int>(mp::ceil_div(K, kchunk));
+  MP_REQUIRE(ws_bytes >= sizeof(float) * static_cast<size_t>(R) * static_cast<size_t>(U) * static_cast<size_t>(used),
+             "mp_dense_splitk_f32: workspace too small");
+  const int64_t gy = mp::ceil_div(R, BM), gx = mp::ceil_div(U, BN);
+  MP_REQUIRE(gx <= 65535 && gy < (int64_t{1} << 31), "mp_dense_splitk_f32: grid too large");
+  dim3 grid(static_cast<unsigned>(gy), static_cast<unsigned>(gx), static_cast<unsigned>(used));
+  hipStream_t s = mp::as_stream(stream);
+  launch_dense<0>(grid, s, x, R, K, W, nullptr, U, 0, 0.0f, out,
+                  DenseExtra{0, 0.0f, nullptr, nullptr, nullptr, nullptr, static_cast<float*>(ws), kchunk});
+  int rc = mp::check_launch("mp_dense_splitk_f32");
+  if (rc != MP_OK) return rc;
+  dense_splitk_reduce_kernel<<<mp::grid_for(R * U), 256, 0, s>>>(static_cast<const float*>(ws), used, R, U, b, act,
+                                                                 act_alpha, out);
+  return mp::check_launch("mp_dense_splitk_f32 (reduce)");
 }
 
 int mp_activation_f32(int act, float act_alpha, const float* x, int64_t n, float* out, mpStream_t stream) {

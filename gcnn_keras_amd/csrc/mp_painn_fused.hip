@@ -32,6 +32,11 @@ __device__ __forceinline__ float ipow(float x, int n) {
   return r;
 }
 
+// v_readlane_b32 of a float register (lane index wave-uniform)
+__device__ __forceinline__ float readlane_f(float v, int l) {
+  return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), l));
+}
+
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
   for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
@@ -195,11 +200,12 @@ __global__ __launch_bounds__(256) void painn_message_kernel(PainnMsgArgs a) {
         my_j = my_j < 0 ? 0 : (my_j >= a.N ? static_cast<int>(a.N) - 1 : my_j);
       }
       for (int u0 = 0; u0 < cnt; u0 += EC) {
-        float sj[EC][3], vj[EC][3];
+        float sj[EC][3], vj[EC][3], meta[EC];
 #pragma unroll
         for (int u = 0; u < EC; ++u) {
           const int slot = u0 + u < cnt ? u0 + u : cnt - 1;   // the tail repeats the last edge (loads only)
           const int j = __builtin_amdgcn_readlane(my_j, slot);
+          const int r = __builtin_amdgcn_readlane(my_r, slot);
           const float* srow = a.s + static_cast<int64_t>(j) * 3 * F + f0;
           const float* vrow = a.v + static_cast<int64_t>(j) * 3 * F + f0;
 #pragma unroll
@@ -207,22 +213,26 @@ __global__ __launch_bounds__(256) void painn_message_kernel(PainnMsgArgs a) {
             sj[u][p] = srow[p * F];
             vj[u][p] = vrow[p * F];
           }
+          // the edge's wave-uniform data in ONE vector load: lanes 0..B-1 its rbf row, B..B+2 r_ij, B+3 the envelope;
+          // handed out with v_readlane below (per-edge scalar loads would each wait for a round trip in front of the FMAs)
+          const float* mp_ = lane < B ? a.rbf + static_cast<int64_t>(r) * B + lane
+                                      : (lane < B + 3 || !a.env) ? a.rij + static_cast<int64_t>(r) * 3 + (lane < B + 3 ? lane - B : 0)
+                                                                 : a.env + r;
+          meta[u] = lane < B + 4 ? *mp_ : 0.0f;
         }
 #pragma unroll
         for (int u = 0; u < EC; ++u) {
           if (u0 + u < cnt) {   // wave-uniform
-            const int r = __builtin_amdgcn_readlane(my_r, u0 + u);
-            const float* rb = a.rbf + static_cast<int64_t>(r) * B;
             float f[3] = {0.0f, 0.0f, 0.0f};
 #pragma unroll
             for (int k = 0; k < MAXB; ++k) {
               if (k < B) {
-                const float x = rb[k];
+                const float x = readlane_f(meta[u], k);
 #pragma unroll
                 for (int p = 0; p < 3; ++p) f[p] = fmaf(x, w[p][k], f[p]);
               }
             }
-            const float envv = a.env ? a.env[r] : 1.0f;
+            const float envv = a.env ? readlane_f(meta[u], B + 3) : 1.0f;
             float sw[3];
 #pragma unroll
             for (int p = 0; p < 3; ++p) {
@@ -233,7 +243,7 @@ __global__ __launch_bounds__(256) void painn_message_kernel(PainnMsgArgs a) {
             ds += sw[0];
 #pragma unroll
             for (int k = 0; k < 3; ++k) {
-              const float rk = a.rij[static_cast<int64_t>(r) * 3 + k];
+              const float rk = readlane_f(meta[u], B + k);
               dv[k] += sw[1] * vj[u][k] + sw[2] * rk;   // (sw2 * v_j) + (sw3 * r_ij)
             }
           }
@@ -321,26 +331,32 @@ __global__ __launch_bounds__(256) void painn_message_bwd_kernel(PainnMsgBwdArgs 
         my_i = my_i < 0 ? 0 : (my_i >= a.N ? static_cast<int>(a.N) - 1 : my_i);
       }
       for (int u0 = 0; u0 < cnt; u0 += EC) {
-        float gz[EC], gdv[EC][3];
+        float gz[EC], gdv[EC][3], meta[EC], metad[EC];
 #pragma unroll
         for (int u = 0; u < EC; ++u) {
           const int slot = u0 + u < cnt ? u0 + u : cnt - 1;
           const int i = __builtin_amdgcn_readlane(my_i, slot);
+          const int r = __builtin_amdgcn_readlane(my_r, slot);
           gz[u] = a.g_ds[static_cast<int64_t>(i) * F + f0];
 #pragma unroll
           for (int k = 0; k < 3; ++k) gdv[u][k] = a.g_dv[(static_cast<int64_t>(i) * 3 + k) * F + f0];
+          // wave-uniform edge data as two vector loads (see the forward kernel): rbf | r_ij | env and rbf' | env'
+          const float* mp_ = lane < B ? a.rbf + static_cast<int64_t>(r) * B + lane
+                                      : (lane < B + 3 || !a.env) ? a.rij + static_cast<int64_t>(r) * 3 + (lane < B + 3 ? lane - B : 0)
+                                                                 : a.env + r;
+          meta[u] = lane < B + 4 ? *mp_ : 0.0f;
+          const float* md_ = (lane < B || !a.envd) ? a.rbfd + static_cast<int64_t>(r) * B + (lane < B ? lane : 0) : a.envd + r;
+          metad[u] = lane < B + 1 ? *md_ : 0.0f;
         }
 #pragma unroll
         for (int u = 0; u < EC; ++u) {
           if (u0 + u < cnt) {   // wave-uniform
             const int r = __builtin_amdgcn_readlane(my_r, u0 + u);
-            const float* rb = a.rbf + static_cast<int64_t>(r) * B;
-            const float* rd = a.rbfd + static_cast<int64_t>(r) * B;
             float f[3] = {0.0f, 0.0f, 0.0f}, fd[3] = {0.0f, 0.0f, 0.0f};
 #pragma unroll
             for (int k = 0; k < MAXB; ++k) {
               if (k < B) {
-                const float x = rb[k], xd = rd[k];
+                const float x = readlane_f(meta[u], k), xd = readlane_f(metad[u], k);
 #pragma unroll
                 for (int p = 0; p < 3; ++p) {
                   f[p] = fmaf(x, w[p][k], f[p]);
@@ -350,11 +366,11 @@ __global__ __launch_bounds__(256) void painn_message_bwd_kernel(PainnMsgBwdArgs 
             }
             float rk[3];
 #pragma unroll
-            for (int k = 0; k < 3; ++k) rk[k] = a.rij[static_cast<int64_t>(r) * 3 + k];
+            for (int k = 0; k < 3; ++k) rk[k] = readlane_f(meta[u], B + k);
             // filter and its derivative w.r.t. the distance (the envelope is a second factor: product rule)
             float wf[3], wd[3];
-            const float envv = a.env ? a.env[r] : 1.0f;
-            const float envdv = (a.env && a.envd) ? a.envd[r] : 0.0f;
+            const float envv = a.env ? readlane_f(meta[u], B + 3) : 1.0f;
+            const float envdv = (a.env && a.envd) ? readlane_f(metad[u], B) : 0.0f;
 #pragma unroll
             for (int p = 0; p < 3; ++p) {
               const float wx = f[p] + bias[p];

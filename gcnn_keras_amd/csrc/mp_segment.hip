@@ -11,6 +11,8 @@
 //    pooling.py:74-76, fused), interior gaps likewise (TF fills missing segment ids with 0).
 // For an unsorted index list the rows are visited through the stable argsort permutation instead of
 // materialising tf.gather(dens, node_order) (pooling.py:68) - the (M,F) copy of the reference never exists.
+#include <type_traits>
+
 #include "mp_common.h"
 
 namespace {
@@ -34,12 +36,15 @@ __device__ __forceinline__ void store_vec(float* p, const float (&v)[W]) {
   }
 }
 
-template <int W, typename PtrT>
-__global__ void segment_reduce_csr_kernel(int op, const float* __restrict__ data, int64_t M, int64_t row_elems,
+// PERM / GATHER / WEIGHT: whether perm, row_index, weight are given - compile-time, because a run-time null test in front
+// of every load of the unrolled rounds becomes a branch per load, and the compiler then waits for each load before the
+// next one is issued (seen in the ISA: global_load, s_waitcnt vmcnt(0), s_cbranch, ... - one round trip per edge).
+template <int W, typename PtrT, bool PERM, bool GATHER, bool WEIGHT>
+__global__ __launch_bounds__(256) void segment_reduce_csr_kernel(int op, const float* __restrict__ data, int64_t M, int64_t row_elems,
                                           const PtrT* __restrict__ ptr, const int32_t* __restrict__ perm,
                                           int64_t n_out, const float* __restrict__ weight, int normalize,
-                                          float* __restrict__ out, const int32_t* __restrict__ row_index = nullptr,
-                                          int64_t n_rows = 0, int act = 0, float act_alpha = 0.0f) {
+                                          float* __restrict__ out, const int32_t* __restrict__ row_index,
+                                          int64_t n_rows, int act, float act_alpha) {
   const int64_t chunks = row_elems / W;
   const int64_t total = n_out * chunks;
   const int64_t stride = static_cast<int64_t>(gridDim.x) * blockDim.x;
@@ -55,30 +60,41 @@ __global__ void segment_reduce_csr_kernel(int op, const float* __restrict__ data
     for (int i = 0; i < W; ++i) acc[i] = 0.0f;
     float wsum = 0.0f;
     const float* base = data + c * W;
-    constexpr int UB = 8;
-    // rows are fetched UB (eight) at a time (independent loads in flight), then folded in edge order
-    for (int64_t e0 = a; e0 < b; e0 += UB) {
+    // rows are fetched UB at a time (independent loads in flight), then folded in edge order.  Eight at a time suits the
+    // short segments of molecular graphs; a segment with 16 or more rows left (hub nodes of a citation graph - Cora's
+    // largest receiver has 129 edges - or a whole graph under PoolingNodes) takes 16 per round: the walk of such a
+    // segment is a chain of dependent round trips (index -> row), and it alone set the kernel's time (37 us at config 5).
+    auto fold = [&](int64_t e0, auto ub_tag) {
+      constexpr int UB = decltype(ub_tag)::value;
+      // Three unconditional phases (tail slots repeat the segment's last row: loads only, masked in the fold): every
+      // phase's loads are independent, so UB of them are in flight at once.  Written as one predicated block per row the
+      // index load of row u+1 sits behind the row load of row u and - vmcnt retires in order - waits for it: measured one
+      // full round trip per edge (0.2 us), 35 us for Cora's 129-edge hub.
       float v[UB][W];
       float wv[UB];
+      int64_t rr[UB], src[UB];
 #pragma unroll
       for (int u = 0; u < UB; ++u) {
-        wv[u] = 1.0f;
-        if (e0 + u < b) {
-          const int64_t r = perm ? static_cast<int64_t>(perm[e0 + u]) : (e0 + u);
-          int64_t src = r;
-          if (row_index) {
-            // gather-on-read: the row of edge r is x[row_index[r]] (GatherNodesOutgoing fused into the reduce)
-            src = row_index[r];
-            src = src < 0 ? 0 : (src >= n_rows ? n_rows - 1 : src);
-          }
-          load_vec<W>(base + src * row_elems, v[u]);
-          if (weight) wv[u] = weight[r];
-        }
+        const int64_t ec = e0 + u < b ? e0 + u : b - 1;
+        rr[u] = PERM ? static_cast<int64_t>(perm[ec]) : ec;
       }
 #pragma unroll
       for (int u = 0; u < UB; ++u) {
+        src[u] = rr[u];
+        if constexpr (GATHER) {
+          // gather-on-read: the row of edge r is x[row_index[r]] (GatherNodesOutgoing fused into the reduce)
+          const int64_t j = row_index[rr[u]];
+          src[u] = j < 0 ? 0 : (j >= n_rows ? n_rows - 1 : j);
+        }
+        wv[u] = 1.0f;
+        if constexpr (WEIGHT) wv[u] = weight[rr[u]];
+      }
+#pragma unroll
+      for (int u = 0; u < UB; ++u) load_vec<W>(base + src[u] * row_elems, v[u]);
+#pragma unroll
+      for (int u = 0; u < UB; ++u) {
         if (e0 + u < b) {
-          if (weight) {
+          if constexpr (WEIGHT) {
             wsum += wv[u];
 #pragma unroll
             for (int i = 0; i < W; ++i) v[u][i] *= wv[u];
@@ -98,13 +114,16 @@ __global__ void segment_reduce_csr_kernel(int op, const float* __restrict__ data
           }
         }
       }
-    }
+    };
+    int64_t e0 = a;
+    for (; b - e0 >= 16; e0 += 16) fold(e0, std::integral_constant<int, 16>());
+    for (; e0 < b; e0 += 8) fold(e0, std::integral_constant<int, 8>());
     if (op == MP_MEAN && b > a) {
       const float cnt = static_cast<float>(b - a);
 #pragma unroll
       for (int i = 0; i < W; ++i) acc[i] = acc[i] / cnt;
     }
-    if (normalize && weight) {
+    if (normalize && WEIGHT) {
 #pragma unroll
       for (int i = 0; i < W; ++i) acc[i] = wsum == 0.0f ? 0.0f : acc[i] / wsum;  // tf.math.divide_no_nan
     }
@@ -180,16 +199,39 @@ __global__ void scatter_relational_kernel(int op, const float* __restrict__ edge
 
 inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 
+// dispatch of the three compile-time flags
+template <int W, typename PtrT>
+void launch_reduce_flags(unsigned grid, hipStream_t s, int op, const float* data, int64_t M, int64_t row_elems,
+                         const PtrT* ptr, const int32_t* perm, int64_t n_out, const float* weight, int normalize,
+                         float* out, const int32_t* row_index, int64_t n_rows, int act, float alpha) {
+#define MP_SEG_LAUNCH(P, G, WT)                                                                                   \
+  segment_reduce_csr_kernel<W, PtrT, P, G, WT><<<grid, 256, 0, s>>>(op, data, M, row_elems, ptr, perm, n_out, weight, \
+                                                                    normalize, out, row_index, n_rows, act, alpha)
+  const int key = (perm ? 4 : 0) | (row_index ? 2 : 0) | (weight ? 1 : 0);
+  switch (key) {
+    case 0: MP_SEG_LAUNCH(false, false, false); break;
+    case 1: MP_SEG_LAUNCH(false, false, true); break;
+    case 2: MP_SEG_LAUNCH(false, true, false); break;
+    case 3: MP_SEG_LAUNCH(false, true, true); break;
+    case 4: MP_SEG_LAUNCH(true, false, false); break;
+    case 5: MP_SEG_LAUNCH(true, false, true); break;
+    case 6: MP_SEG_LAUNCH(true, true, false); break;
+    default: MP_SEG_LAUNCH(true, true, true); break;
+  }
+#undef MP_SEG_LAUNCH
+}
+
 template <typename PtrT>
 int launch_segment_reduce(int op, const float* data, int64_t M, int64_t row_elems, const PtrT* ptr,
                           const int32_t* perm, int64_t N_out, const float* weight, int normalize, float* out,
-                          hipStream_t s, const char* what) {
+                          hipStream_t s, const char* what, const int32_t* row_index = nullptr, int64_t n_rows = 0,
+                          int act = 0, float alpha = 0.0f) {
   if (row_elems % 4 == 0 && aligned16(data) && aligned16(out)) {
-    segment_reduce_csr_kernel<4, PtrT><<<mp::grid_for(N_out * (row_elems / 4)), 256, 0, s>>>(
-        op, data, M, row_elems, ptr, perm, N_out, weight, normalize, out);
+    launch_reduce_flags<4, PtrT>(mp::grid_for(N_out * (row_elems / 4)), s, op, data, M, row_elems, ptr, perm, N_out,
+                                 weight, normalize, out, row_index, n_rows, act, alpha);
   } else {
-    segment_reduce_csr_kernel<1, PtrT><<<mp::grid_for(N_out * row_elems), 256, 0, s>>>(
-        op, data, M, row_elems, ptr, perm, N_out, weight, normalize, out);
+    launch_reduce_flags<1, PtrT>(mp::grid_for(N_out * row_elems), s, op, data, M, row_elems, ptr, perm, N_out, weight,
+                                 normalize, out, row_index, n_rows, act, alpha);
   }
   return mp::check_launch(what);
 }
@@ -218,15 +260,9 @@ int mp_gather_segment_reduce_csr_f32(int op, const float* x, int64_t N, int64_t 
   MP_REQUIRE(act >= MP_ACT_LINEAR && act <= MP_ACT_SOFTPLUS2, "mp_gather_segment_reduce_csr_f32: unknown activation");
   if (N_out == 0) return MP_OK;
   MP_REQUIRE(ptr && out && (M == 0 || (x && send && N > 0)), "mp_gather_segment_reduce_csr_f32: null pointer");
-  hipStream_t s = mp::as_stream(stream);
-  if (row_elems % 4 == 0 && aligned16(x) && aligned16(out)) {
-    segment_reduce_csr_kernel<4, int32_t><<<mp::grid_for(N_out * (row_elems / 4)), 256, 0, s>>>(
-        op, x, M, row_elems, ptr, perm, N_out, weight, normalize_by_weight, out, send, N, act, act_alpha);
-  } else {
-    segment_reduce_csr_kernel<1, int32_t><<<mp::grid_for(N_out * row_elems), 256, 0, s>>>(
-        op, x, M, row_elems, ptr, perm, N_out, weight, normalize_by_weight, out, send, N, act, act_alpha);
-  }
-  return mp::check_launch("mp_gather_segment_reduce_csr_f32");
+  return launch_segment_reduce<int32_t>(op, x, M, row_elems, ptr, perm, N_out, weight, normalize_by_weight, out,
+                                        mp::as_stream(stream), "mp_gather_segment_reduce_csr_f32", send, N, act,
+                                        act_alpha);
 }
 
 int mp_pool_graph_f32(int op, const float* x, const int64_t* row_splits, int64_t G, int64_t row_elems,

@@ -245,6 +245,9 @@ class GraphedModel:
         saved = [r.mode for r in routes]
         for r in routes:
             r.mode = "eager"
+        auto = [m for m in (model, getattr(model, "energy_model", None)) if getattr(m, "auto_graph", False)]
+        for m in auto:          # a model that graphs itself must not replay its own graph inside this capture
+            m.auto_graph = False
         try:
             with torch.cuda.stream(self.stream), torch.set_grad_enabled(self.grad):
                 for _ in range(3):
@@ -257,6 +260,8 @@ class GraphedModel:
         finally:
             for r, mode in zip(routes, saved):
                 r.mode = mode
+            for m in auto:
+                m.auto_graph = True
 
     def __call__(self):
         self.graph.replay()

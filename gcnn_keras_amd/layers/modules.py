@@ -22,6 +22,14 @@ def _dense_raw(x, kernel, bias, act_code, alpha):
     xc = x.contiguous()
     rows = xc.numel() // max(k, 1)
     out = torch.empty(tuple(x.shape[:-1]) + (u,), dtype=torch.float32, device=x.device)
+    tiles = -(-rows // 64) * -(-u // 64)
+    if tiles <= 128 and k >= 512:
+        # few 64x64 output tiles, long contraction (GCN's 1433 input features): cut k over workgroups to fill the chip
+        splits = max(1, min(256 // tiles, k // 128, 64))
+        ws = torch.empty((splits, max(rows, 1), u), dtype=torch.float32, device=x.device)
+        _ffi.call("mp_dense_splitk_f32", _ffi.ptr(xc), rows, k, _ffi.ptr(kernel), _ffi.ptr(bias), u, act_code,
+                  float(alpha), splits, _ffi.ptr(ws), ws.numel() * 4, _ffi.ptr(out), _ffi.stream())
+        return out
     _ffi.call("mp_dense_f32", _ffi.ptr(xc), rows, k, _ffi.ptr(kernel), _ffi.ptr(bias), u, act_code, float(alpha),
               _ffi.ptr(out), _ffi.stream())
     return out

@@ -97,4 +97,5 @@ def make_model(name: str = None, inputs: list = None, input_embedding: dict = No
                   config={"depth": depth, "edge_initialize": edge_initialize, "edge_dense": edge_dense,
                           "node_dense": node_dense})
     model.__kgcnn_model_version__ = __model_version__
+    model.auto_graph = True   # re-bound inputs replay the whole layer sequence from one HIP graph (model/utils.py)
     return model

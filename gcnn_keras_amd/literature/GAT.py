@@ -82,6 +82,7 @@ def make_model(inputs: list = None, input_embedding: dict = None, attention_args
     model = Model(name, forward, [embed_n, embed_e, dense0] + flat_heads + [out_mlp],
                   config={"depth": depth, "attention_args": attention_args, "attention_heads_num": attention_heads_num})
     model.__kgcnn_model_version__ = __model_version__
+    model.auto_graph = True   # re-bound inputs replay the whole layer sequence from one HIP graph (model/utils.py)
     return model
 
 

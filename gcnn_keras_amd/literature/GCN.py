@@ -67,4 +67,5 @@ def make_model(inputs: list = None, input_embedding: dict = None, depth: int = N
     model = Model(name, forward, [embed_n, embed_e, dense0] + gcns + [out_mlp], config={"depth": depth,
                                                                                          "gcn_args": gcn_args})
     model.__kgcnn_model_version__ = __model_version__
+    model.auto_graph = True   # re-bound inputs replay the whole layer sequence from one HIP graph (model/utils.py)
     return model

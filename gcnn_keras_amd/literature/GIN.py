@@ -84,4 +84,5 @@ def make_model(inputs: list = None, input_embedding: dict = None, depth: int = N
     model = Model(name, forward, [embed_n, dense0] + [lay for pair in zip(gins, mlps) for lay in pair] + lasts + [out_mlp],
                   config={"depth": depth, "gin_mlp": gin_mlp, "gin_args": gin_args})
     model.__kgcnn_model_version__ = __model_version__
+    model.auto_graph = True   # re-bound inputs replay the whole layer sequence from one HIP graph (model/utils.py)
     return model

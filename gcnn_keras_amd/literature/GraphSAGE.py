@@ -92,4 +92,5 @@ def make_model(inputs: list = None, input_embedding: dict = None, node_mlp_args:
     model = Model(name, forward, layers + [out_mlp], config={"depth": depth, "node_mlp_args": node_mlp_args,
                                                              "edge_mlp_args": edge_mlp_args})
     model.__kgcnn_model_version__ = __model_version__
+    model.auto_graph = True   # re-bound inputs replay the whole layer sequence from one HIP graph (model/utils.py)
     return model

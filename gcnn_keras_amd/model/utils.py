@@ -59,16 +59,81 @@ def update_model_kwargs(model_default, update_recursive=inf):
 
 
 class Model:
-    """Minimal stand-in for ``ks.models.Model``: an ordered list of layers plus a forward function."""
+    """Minimal stand-in for ``ks.models.Model``: an ordered list of layers plus a forward function.
 
-    def __init__(self, name, forward, layers, config=None):
+    ``auto_graph``: a layer-path model issues one engine call per Keras layer (a dozen to a few hundred launches), and at
+    QM9 / Cora sizes the host cannot keep the GPU busy that way.  With ``auto_graph=True`` the model remembers, per
+    distinct input set (identified by the storage of its tensors), how often it was called: the first call runs eagerly
+    (building and caching the index plans on the ragged inputs), the second captures the same call sequence into ONE HIP
+    graph (``engine.GraphedModel``), later calls replay it and return a fresh copy of the output.  Calls that ask for
+    gradients, pass keyword arguments, or whose capture fails (a layer that needs a host read per call) stay eager.
+    """
+
+    def __init__(self, name, forward, layers, config=None, auto_graph=False, max_graphs=4):
         self.name = name
         self._forward = forward
         self.layers = layers
         self.config = config or {}
+        self.auto_graph = bool(auto_graph)
+        self.max_graphs = int(max_graphs)
+        self._graphs = {}      # input identity -> [calls, GraphedModel | None | False]
+        self.last_route = None  # "eager" | "graph"
 
     def __call__(self, inputs, **kwargs):
+        if self.auto_graph and not kwargs:
+            key = self._graph_key(inputs)
+            if key is not None:
+                return self._call_graphed(key, inputs)
+        self.last_route = "eager"
         return self._forward(inputs, **kwargs)
+
+    # -- graph replay of re-bound inputs ----------------------------------------------------------------------------------
+    @staticmethod
+    def _graph_key(inputs):
+        import torch
+        from ..ragged import RaggedTensor
+        if not torch.cuda.is_available() or not isinstance(inputs, (list, tuple)):
+            return None
+        key = []
+        for x in inputs:
+            parts = (x.values, x.row_splits) if isinstance(x, RaggedTensor) else (x,)
+            for t in parts:
+                if not torch.is_tensor(t) or not t.is_cuda or (torch.is_grad_enabled() and t.requires_grad):
+                    return None
+                key.append((t.data_ptr(), tuple(t.shape), t._version if t.dtype == torch.int64 else 0))
+        return tuple(key)
+
+    def _call_graphed(self, key, inputs):
+        from ..ragged import RaggedTensor
+        entry = self._graphs.get(key)
+        if entry is None:
+            while len(self._graphs) >= self.max_graphs:
+                self._graphs.pop(next(iter(self._graphs)))
+            entry = self._graphs[key] = [0, None, inputs]   # the entry keeps the inputs alive: addresses stay an identity
+        entry[0] += 1
+        if entry[0] == 1 or entry[1] is False:
+            self.last_route = "eager"
+            return self._forward(inputs)
+        if entry[1] is None:
+            from ..engine import GraphedModel
+            try:
+                entry[1] = GraphedModel(self._forward, inputs, grad=False)
+            except Exception:   # e.g. a layer that reads a size back per call cannot be captured: stay eager
+                import torch
+                torch.cuda.synchronize()
+                entry[1] = False
+                self.last_route = "eager"
+                return self._forward(inputs)
+        out = entry[1]()
+        self.last_route = "graph"
+        if isinstance(out, RaggedTensor):
+            return out.with_values(out.values.clone())
+        if isinstance(out, (list, tuple)):
+            return type(out)(o.clone() if hasattr(o, "clone") else o for o in out)
+        return out.clone()
+
+    def release_graphs(self):
+        self._graphs.clear()
 
     predict = __call__
 

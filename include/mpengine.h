@@ -161,6 +161,14 @@ int mp_dense_ex_f32(const float* x, int64_t R, int64_t K, const float* W, const 
                     float act_alpha, int in_mode, int in_act, float in_alpha, const float* in_pre, const float* addend,
                     float* out_pre, const float* grad_pre, float* out, mpStream_t stream);
 
+/* mp_dense_f32 for few output tiles and a long contraction (GCN's first layer, kgcnn/literature/GCN.py:95:
+ * (2708,1433) x (1433,64) = 43 tiles of 64x64 for 256 CUs): the k range is cut into `splits` slices computed by separate
+ * workgroups into the workspace (splits * R * U floats), a second kernel adds the slices in order and applies bias and
+ * activation - deterministic, no atomics. */
+int mp_dense_splitk_workspace_bytes(int64_t R, int64_t U, int splits, size_t* bytes_out_host);
+int mp_dense_splitk_f32(const float* x, int64_t R, int64_t K, const float* W, const float* b, int64_t U, int act,
+                        float act_alpha, int splits, void* ws, size_t ws_bytes, float* out, mpStream_t stream);
+
 int mp_activation_f32(int act, float act_alpha, const float* x, int64_t n, float* out, mpStream_t stream);
 int mp_softmax_rows_f32(const float* x, int64_t R, int64_t C, float* out, mpStream_t stream);
 /* GraphLayerNormalization over the last axis of the values (kgcnn/layers/norm.py:8-110 = Keras LayerNormalization):

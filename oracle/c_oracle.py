@@ -5,7 +5,7 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-_LIB = os.path.join(_HERE, "libmp_oracle.so")
+_LIB = os.environ.get("MP_ORACLE_LIB") or os.path.join(_HERE, "libmp_oracle.so")   # override: `make -C oracle asan`
 _lib = None
 
 
