@@ -21,6 +21,7 @@ MP_FLAG_OOB, MP_FLAG_UNSORTED_COL0, MP_FLAG_UNSORTED_COL1 = 1, 2, 4
 ACTIVATION_CODES = {
     None: 0, "linear": 0, "relu": 1, "kgcnn>shifted_softplus": 2, "shifted_softplus": 2, "softplus": 3,
     "swish": 4, "sigmoid": 5, "tanh": 6, "kgcnn>leaky_relu": 7, "leaky_relu": 7, "kgcnn>softplus2": 8, "softplus2": 8,
+    "selu": 9,
 }
 
 P = c_void_p
@@ -78,6 +79,9 @@ _SIGNATURES = {
                                      c_size_t, P],
     "mp_cfconv_gauss_diag_f32": [P, c_int64, P, c_int, c_float, c_float, c_float, P, P, P, P, c_int64, P, P, P],
     "mp_painn_message_fused_f32": [P, P, c_int64, P, c_int, P, P, P, P, P, P, P, c_int64, P, P, P],
+    "mp_lstm_zero_state_f32": [P, c_int64, c_int64, c_int, c_int, P, P],
+    "mp_gru_combine_f32": [P, P, P, c_int64, c_int64, c_int, c_int, P, P],
+    "mp_batched_matvec_f32": [P, P, c_int64, c_int64, c_int64, P, P],
     "mp_painn_stage0_f32": [P, c_int64, P, c_int, c_float, P, P, P, c_int64, P, P, c_int64, P, P, c_int, c_float, c_int,
                             c_float, P, P, P, P, P, P, P, P, P, P],
     "mp_painn_message_f32": [P, P, c_int64, P, c_int, P, P, P, P, P, P, P, c_int64, P, P, P, P],

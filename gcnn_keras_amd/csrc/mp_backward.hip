@@ -119,7 +119,7 @@ extern "C" {
 
 int mp_activation_grad_f32(int act, float act_alpha, const float* pre, const float* gy, int64_t n, float* out,
                            mpStream_t stream) {
-  MP_REQUIRE(n >= 0 && act >= MP_ACT_LINEAR && act <= MP_ACT_SOFTPLUS2, "mp_activation_grad_f32: bad arguments");
+  MP_REQUIRE(n >= 0 && act >= MP_ACT_LINEAR && act <= MP_ACT_LAST, "mp_activation_grad_f32: bad arguments");
   if (n == 0) return MP_OK;
   MP_REQUIRE(pre && gy && out, "mp_activation_grad_f32: null pointer");
   activation_grad_kernel<<<mp::grid_for(n), 256, 0, mp::as_stream(stream)>>>(act, act_alpha, pre, gy, n, out);

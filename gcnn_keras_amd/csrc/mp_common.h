@@ -85,6 +85,7 @@ __device__ __forceinline__ float mp_apply_act(int act, float alpha, float v) {
     case MP_ACT_TANH: return tanhf(v);
     case MP_ACT_LEAKY_RELU: return v >= 0.0f ? v : alpha * v;
     case MP_ACT_SOFTPLUS2: return fmaxf(v, 0.0f) + logf(0.5f * expf(-fabsf(v)) + 0.5f);
+    case MP_ACT_SELU: return 1.05070098f * (v > 0.0f ? v : 1.67326324f * (expf(v) - 1.0f));
     default: return v;
   }
 }
@@ -101,6 +102,7 @@ __device__ __forceinline__ float mp_act_grad(int act, float alpha, float x) {
     case MP_ACT_SIGMOID: { const float s = mp_sigmoid(x); return s * (1.0f - s); }
     case MP_ACT_TANH: { const float t = tanhf(x); return 1.0f - t * t; }
     case MP_ACT_LEAKY_RELU: return x >= 0.0f ? 1.0f : alpha;
+    case MP_ACT_SELU: return 1.05070098f * (x > 0.0f ? 1.0f : 1.67326324f * expf(x));
     default: return 1.0f;
   }
 }

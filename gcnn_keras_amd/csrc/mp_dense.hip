@@ -280,7 +280,7 @@ int mp_dense_f32(const float* x, int64_t R, int64_t K, const float* W, const flo
                  float act_alpha, float* out, mpStream_t stream) {
   MP_REQUIRE(R >= 0 && K >= 1 && U >= 1, "mp_dense_f32: bad sizes R=%lld K=%lld U=%lld", (long long)R, (long long)K,
              (long long)U);
-  MP_REQUIRE(act >= MP_ACT_LINEAR && act <= MP_ACT_SOFTPLUS2, "mp_dense_f32: unknown activation %d", act);
+  MP_REQUIRE(act >= MP_ACT_LINEAR && act <= MP_ACT_LAST, "mp_dense_f32: unknown activation %d", act);
   if (R == 0) return MP_OK;
   MP_REQUIRE(x && W && out, "mp_dense_f32: null pointer");
   const int64_t gy = mp::ceil_div(R, BM), gx = mp::ceil_div(U, BN);
@@ -296,7 +296,7 @@ int mp_dense_ex_f32(const float* x, int64_t R, int64_t K, const float* W, const 
                     float* out_pre, const float* grad_pre, float* out, mpStream_t stream) {
   MP_REQUIRE(R >= 0 && K >= 1 && U >= 1, "mp_dense_ex_f32: bad sizes R=%lld K=%lld U=%lld", (long long)R, (long long)K,
              (long long)U);
-  MP_REQUIRE(act >= MP_ACT_LINEAR && act <= MP_ACT_SOFTPLUS2 && in_act >= MP_ACT_LINEAR && in_act <= MP_ACT_SOFTPLUS2,
+  MP_REQUIRE(act >= MP_ACT_LINEAR && act <= MP_ACT_LAST && in_act >= MP_ACT_LINEAR && in_act <= MP_ACT_LAST,
              "mp_dense_ex_f32: unknown activation");
   MP_REQUIRE(in_mode >= 0 && in_mode <= 2 && (in_mode != 2 || in_pre != nullptr), "mp_dense_ex_f32: bad prologue mode");
   if (R == 0) return MP_OK;
@@ -321,7 +321,7 @@ int mp_dense_splitk_workspace_bytes(int64_t R, int64_t U, int splits, size_t* by
 int mp_dense_splitk_f32(const float* x, int64_t R, int64_t K, const float* W, const float* b, int64_t U, int act,
                         float act_alpha, int splits, void* ws, size_t ws_bytes, float* out, mpStream_t stream) {
   MP_REQUIRE(R >= 0 && K >= 1 && U >= 1 && splits >= 1 && splits <= 64, "mp_dense_splitk_f32: bad sizes");
-  MP_REQUIRE(act >= MP_ACT_LINEAR && act <= MP_ACT_SOFTPLUS2, "mp_dense_splitk_f32: unknown activation %d", act);
+  MP_REQUIRE(act >= MP_ACT_LINEAR && act <= MP_ACT_LAST, "mp_dense_splitk_f32: unknown activation %d", act);
   if (R == 0) return MP_OK;
   MP_REQUIRE(x && W && out && ws, "mp_dense_splitk_f32: null pointer");
   // k range of a slice: a multiple of the k tile; trailing slices that would be empty are dropped
@@ -344,7 +344,7 @@ int mp_dense_splitk_f32(const float* x, int64_t R, int64_t K, const float* W, co
 
 int mp_activation_f32(int act, float act_alpha, const float* x, int64_t n, float* out, mpStream_t stream) {
   MP_REQUIRE(n >= 0, "mp_activation_f32: bad size");
-  MP_REQUIRE(act >= MP_ACT_LINEAR && act <= MP_ACT_SOFTPLUS2, "mp_activation_f32: unknown activation %d", act);
+  MP_REQUIRE(act >= MP_ACT_LINEAR && act <= MP_ACT_LAST, "mp_activation_f32: unknown activation %d", act);
   if (n == 0) return MP_OK;
   MP_REQUIRE(x && out, "mp_activation_f32: null pointer");
   activation_kernel<<<mp::grid_for(n), 256, 0, mp::as_stream(stream)>>>(act, act_alpha, x, n, out);

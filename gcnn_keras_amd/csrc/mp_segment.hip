@@ -257,7 +257,7 @@ int mp_gather_segment_reduce_csr_f32(int op, const float* x, int64_t N, int64_t 
                                      mpStream_t stream) {
   MP_REQUIRE(op >= MP_SUM && op <= MP_MIN, "mp_gather_segment_reduce_csr_f32: unknown op %d", op);
   MP_REQUIRE(M >= 0 && N >= 0 && N_out >= 0 && row_elems >= 1, "mp_gather_segment_reduce_csr_f32: bad sizes");
-  MP_REQUIRE(act >= MP_ACT_LINEAR && act <= MP_ACT_SOFTPLUS2, "mp_gather_segment_reduce_csr_f32: unknown activation");
+  MP_REQUIRE(act >= MP_ACT_LINEAR && act <= MP_ACT_LAST, "mp_gather_segment_reduce_csr_f32: unknown activation");
   if (N_out == 0) return MP_OK;
   MP_REQUIRE(ptr && out && (M == 0 || (x && send && N > 0)), "mp_gather_segment_reduce_csr_f32: null pointer");
   return launch_segment_reduce<int32_t>(op, x, M, row_elems, ptr, perm, N_out, weight, normalize_by_weight, out,

@@ -69,11 +69,17 @@ class Layer:
             fan_in, fan_out = fan if fan is not None else (shape[0], shape[-1])
             limit = np.sqrt(6.0 / (fan_in + fan_out))
             arr = rng.uniform(-limit, limit, size=shape).astype(np.float32)
+        elif initializer in ("orthogonal", "Orthogonal"):
+            # Keras Orthogonal: QR of a normal matrix (sign-fixed), rows >= cols handled by transposition
+            rows, cols = int(np.prod(shape[:-1])), shape[-1]
+            q, r = np.linalg.qr(rng.normal(size=(max(rows, cols), min(rows, cols))))
+            q = q * np.sign(np.diag(r))
+            arr = (q if rows >= cols else q.T).reshape(shape).astype(np.float32)
         elif initializer in ("uniform", "RandomUniform", "random_uniform"):
             arr = rng.uniform(-0.05, 0.05, size=shape).astype(np.float32)
         else:
             raise ValueError("Unsupported initializer %r" % (initializer,))
-        t = torch.from_numpy(arr).to(device)
+        t = torch.from_numpy(np.array(arr, dtype=np.float32, order="C")).to(device)   # C order, 0-d stays 0-d
         self._weights.append((name, t))
         return t
 

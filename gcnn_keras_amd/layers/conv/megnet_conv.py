@@ -48,6 +48,22 @@ class MEGnetBlock(GraphBaseLayer):
         self.lay_conc_u = LazyConcatenate(axis=-1)
         self.lay_phi_u, self.lay_phi_u_1, self.lay_phi_u_2 = chain(self.env_embed)
 
+    def build(self, input_shape):
+        """Weights of the three Dense chains (so ``set_weights`` works before a first call): the edge chain reads
+        [n_i || n_j, e, u], the node chain [pooled e', n, u], the state chain [pooled e', pooled n', u]."""
+        super().build(input_shape)
+        fn, fe, fu = int(input_shape[0][-1]), int(input_shape[1][-1]), int(input_shape[3][-1])
+
+        def build_chain(layers, widths, in_dim):
+            for lay, w in zip(layers, widths):
+                lay.ensure_built((None, None, in_dim))
+                in_dim = w
+
+        build_chain((self.lay_phi_e, self.lay_phi_e_1, self.lay_phi_e_2), self.edge_embed, 2 * fn + fe + fu)
+        build_chain((self.lay_phi_n, self.lay_phi_n_1, self.lay_phi_n_2), self.node_embed, self.edge_embed[-1] + fn + fu)
+        build_chain((self.lay_phi_u, self.lay_phi_u_1, self.lay_phi_u_2), self.env_embed,
+                    self.edge_embed[-1] + self.node_embed[-1] + fu)
+
     @staticmethod
     def _run(layers, x, **kwargs):
         for lay in layers:

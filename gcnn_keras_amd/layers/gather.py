@@ -36,9 +36,9 @@ def _gather_rows_raw(values, plan, colsel):
 
 class GatherEmbedding(GraphBaseLayer):
     r"""Gather node embeddings for every index of an edge ``(i, j)``; default output ``[x_i || x_j]`` of shape
-    ``(batch, [M], 2*F)`` (kgcnn/layers/gather.py:9-149).  Only the disjoint fast path of the reference
-    (gather.py:69-99: ragged rank 1, ``axis == 1``, concat / split axis ``None`` or 2) exists here; other axes
-    raise ``NotImplementedError`` instead of falling back to ``tf.gather(batch_dims=1)``."""
+    ``(batch, [M], 2*F)`` (kgcnn/layers/gather.py:9-149).  The reference's disjoint fast path (gather.py:69-99:
+    ``axis == 1``, concat / split axis ``None`` or 2) is one gather kernel; other concat / split axes take the general
+    route of gather.py:121-138 (same gather + strided re-arrangement); only ``axis != 1`` (ragged rank 2 in TF) raises."""
 
     def __init__(self, axis: int = 1, concat_axis: int = 2, split_axis: int = None, split_indices: list = None,
                  concat_indices: list = None, node_indexing: str = "sample", **kwargs):
@@ -59,11 +59,15 @@ class GatherEmbedding(GraphBaseLayer):
     def call(self, inputs, **kwargs):
         r"""inputs: ``[embeddings (batch, [N], F), tensor_index (batch, [M], K)]``."""
         nodes, idx = self.assert_ragged_input_rank(list(inputs))
-        if self.axis != 1 or self.concat_axis not in [None, 2] or self.split_axis not in [None, 2]:
-            raise NotImplementedError("Only the disjoint fast path (axis=1, concat/split axis in {None, 2}) is built.")
+        if self.axis != 1:
+            # tf.gather(batch_dims=1, axis > 1) picks FEATURE positions per edge and yields ragged rank 2 - no kgcnn model
+            # uses it, and this package's ragged carrier is rank 1
+            raise NotImplementedError("GatherEmbedding gathers along the node axis (axis=1)")
         plan = idx.index_plan(nodes)
         if self.ragged_validate:
             plan.validate()
+        if self.concat_axis not in [None, 2] or self.split_axis not in [None, 2]:
+            return self._general(nodes, idx, plan)
         if self.concat_axis == 2:
             cols = list(self.concat_indices) if self.concat_indices else list(range(plan.K))
             out = gather_rows(nodes.values, plan, cols)  # (M, K, F...)
@@ -75,6 +79,31 @@ class GatherEmbedding(GraphBaseLayer):
             cols = list(self.split_indices) if self.split_indices else list(range(plan.K))
             return [idx.with_values(gather_rows(nodes.values, plan, [c])[:, 0].contiguous()) for c in cols]
         return idx.with_values(gather_rows(nodes.values, plan, list(range(plan.K))))
+
+    def _general(self, nodes, idx, plan):
+        """The reference's general route (gather.py:121-138): ``out = tf.gather(nodes, index, batch_dims=1, axis=1)`` of
+        shape ``(batch, [M], K, F...)``, then ``tf.gather(out, i, axis)`` for every concat / split index along ANY later
+        axis and ``tf.concat`` along that same axis.  The gather is the engine kernel; picking index ``i`` along a later
+        axis and re-joining are strided copies of the gathered values (layout only)."""
+        out = gather_rows(nodes.values, plan, list(range(plan.K)))        # values of (batch, [M], K, F...)
+        rank = out.dim() + 1                                              # rank of the ragged tensor incl. batch axis
+
+        def positive(axis):
+            axis = axis + rank if axis < 0 else axis
+            if not 2 <= axis < rank:
+                raise ValueError("axis %d is not a dense axis of the gathered tensor of rank %d" % (axis, rank))
+            return axis - 1                                               # same axis on the values tensor
+
+        if self.concat_axis is not None:
+            ax = positive(self.concat_axis)
+            picks = list(self.concat_indices) if self.concat_indices else list(range(int(out.shape[ax])))
+            parts = [out.select(ax, i) for i in picks]                    # tf.gather(out, i, axis): drops the axis
+            if ax >= parts[0].dim():   # tf.concat raises the same way: the picked tensors lost that axis
+                raise ValueError("concat_axis %d is past the last axis once an index is picked along it" % self.concat_axis)
+            return idx.with_values(torch.cat(parts, dim=ax).contiguous())
+        ax = positive(self.split_axis)
+        picks = list(self.split_indices) if self.split_indices else list(range(int(out.shape[ax])))
+        return [idx.with_values(out.select(ax, i).contiguous()) for i in picks]
 
     def get_config(self):
         config = super().get_config()

@@ -41,7 +41,9 @@ enum mp_reduce_op { MP_SUM = 0, MP_MEAN = 1, MP_MAX = 2, MP_MIN = 3 };
 enum mp_activation {
   MP_ACT_LINEAR = 0, MP_ACT_RELU = 1, MP_ACT_SHIFTED_SOFTPLUS = 2, MP_ACT_SOFTPLUS = 3, MP_ACT_SWISH = 4,
   MP_ACT_SIGMOID = 5, MP_ACT_TANH = 6, MP_ACT_LEAKY_RELU = 7,
-  MP_ACT_SOFTPLUS2 = 8 /* kgcnn/ops/activ.py:19-29: relu(x) + log(0.5 exp(-|x|) + 0.5) */
+  MP_ACT_SOFTPLUS2 = 8, /* kgcnn/ops/activ.py:19-29: relu(x) + log(0.5 exp(-|x|) + 0.5) */
+  MP_ACT_SELU = 9,      /* Keras "selu" (kgcnn/literature/NMPN.py:41): scale * (x > 0 ? x : alpha * (exp(x) - 1)) */
+  MP_ACT_LAST = MP_ACT_SELU
 };
 
 enum mp_binary_op { MP_ADD = 0, MP_SUB = 1, MP_MUL = 2 };
@@ -269,6 +271,20 @@ int mp_painn_message_fused_f32(const float* s, const float* v, int64_t N, const 
                                const float* rij, const float* Ww, const float* bw, const int32_t* ptr,
                                const int32_t* perm, const int32_t* send, int64_t M, float* ds, float* dv,
                                mpStream_t stream);
+
+/* ---------------------------------------------------------------- recurrent / edge-network pieces -------- */
+/* One Keras LSTM step from the zero state, as PoolingSet2Set runs it (kgcnn/layers/pool/set2set.py:190: a stateless LSTM
+ * layer called on a length-1 sequence): z (R,4U) = x kernel + bias in Keras gate order [i | f | c | o];
+ * out (R,U) = rec(z_o) * act(rec(z_i) * act(z_c))  (h0 = c0 = 0: the forget gate and the recurrent kernel drop out). */
+int mp_lstm_zero_state_f32(const float* z, int64_t R, int64_t U, int act, int rec_act, float* out, mpStream_t stream);
+/* Keras GRUCell combine, reset_after = True (kgcnn/layers/conv/mpnn_conv.py:193 GRUUpdate): mx (R,3U) = x kernel + b_in,
+ * mh (R,3U) = h recurrent_kernel + b_rec, gate order [z | r | h]:
+ * zg = rec(mx_z + mh_z), rg = rec(mx_r + mh_r), hh = act(mx_h + rg * mh_h), out = zg * h + (1 - zg) * hh. */
+int mp_gru_combine_f32(const float* mx, const float* mh, const float* h, int64_t R, int64_t U, int act, int rec_act,
+                       float* out, mpStream_t stream);
+/* MatMulMessages, kgcnn/layers/conv/mpnn_conv.py:111 (tf.keras.backend.batch_dot): out[m] = mat[m] (Ro,C) . vec[m] (C). */
+int mp_batched_matvec_f32(const float* mat, const float* vec, int64_t M, int64_t Ro, int64_t C, float* out,
+                          mpStream_t stream);
 
 /* ---------------------------------------------------------------- fused PaiNN path (+ reverse pass) ------ */
 /* Stage 0 of kgcnn/literature/PAiNN.py:100-119 in one launch: OptionalInputEmbedding (z0 (N,128)), EquivariantInitialize

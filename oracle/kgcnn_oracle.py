@@ -300,6 +300,8 @@ ACTIVATIONS = {
     "kgcnn>leaky_relu": leaky_relu,
     "kgcnn>softplus2": softplus2,
     "softplus2": softplus2,
+    "selu": lambda x: (np.asarray(x).dtype.type(1.05070098) * np.where(
+        np.asarray(x) > 0, x, np.asarray(x).dtype.type(1.67326324) * (np.exp(np.minimum(x, 0)) - 1))).astype(np.asarray(x).dtype),
 }
 
 
@@ -1026,6 +1028,162 @@ def megnet_block(node, edge, idx, env, p, act="kgcnn>softplus2", pooling_method=
     vs = pooling_nodes(vp, pooling_method=pooling_method)
     up = chain(np.concatenate([es, vs, env], axis=-1), "phi_u")
     return vp, ep, up
+
+
+# ----------------------------------------------------------------------------------------
+# kgcnn/layers/pool/set2set.py, kgcnn/layers/conv/mpnn_conv.py, kgcnn/literature/{Megnet,NMPN}.py
+# parity unpinned: the reference holds no value fixture for these; the LSTM / GRU arithmetic is Keras' documented cell
+# math (keras/layers/rnn/{lstm,gru}.py: gate order i,f,c,o resp. z,r,h; GRU reset_after=True), restated here.
+# ----------------------------------------------------------------------------------------
+
+def pooling_set2set(r, kernel, bias, T=3, pooling_method="mean", init_qstar="mean", act="tanh", rec_act="sigmoid"):
+    """``PoolingSet2Set.call``, kgcnn/layers/pool/set2set.py:172-199 (+ ``init_qstar_mean`` :245-263).  The reference
+    calls a stateless Keras LSTM on a length-1 sequence in every round: one LSTM step from h0 = c0 = 0, so
+    ``q = o * act(i * act(z_c))`` with ``z = q* kernel + bias`` (the recurrent kernel multiplies h0 = 0).
+    Returns ``(G, 1, 2 * channels)``."""
+    m = np.asarray(r.values)
+    dt = m.dtype
+    ids = value_rowids(r)
+    lens = row_lengths(r)
+    g, f = len(lens), m.shape[1]
+    pool = (lambda x: x.mean(axis=1)) if pooling_method == "mean" else (lambda x: x.sum(axis=1))
+
+    def attend(q):
+        et = pool(m * np.repeat(q, lens, axis=0))                              # f_et, :201-213
+        mx = np.full(g, -np.inf, dt)
+        np.maximum.at(mx, ids, et)                                             # segment_max, :221-225
+        at = np.exp(et - np.repeat(mx, lens))
+        norm = np.zeros(g, dt)
+        np.add.at(norm, ids, at)                                               # segment_sum
+        with np.errstate(divide="ignore"):
+            inv = np.where(norm == 0, dt.type(0), dt.type(1) / norm)           # reciprocal_no_nan, :231
+        at = np.repeat(inv, lens) * at
+        rt = np.zeros((g, f), dt)
+        for n in range(m.shape[0]):                                            # segment_sum in row order
+            rt[ids[n]] += m[n] * at[n]
+        return rt
+
+    if init_qstar == "mean":
+        q = np.zeros((g, f), dt)
+        for n in range(m.shape[0]):
+            q[ids[n]] += m[n]
+        q = q / np.maximum(lens, 1).astype(dt)[:, None]
+        qstar = np.concatenate([q, attend(q)], axis=1)
+    else:
+        qstar = np.zeros((g, 2 * f), dt)
+    for _ in range(T):
+        z = np.matmul(qstar, kernel.astype(dt)) + (bias.astype(dt) if bias is not None else 0)
+        zi, _, zc, zo = np.split(z, 4, axis=1)
+        c = activation(rec_act, zi) * activation(act, zc)
+        q = (activation(rec_act, zo) * activation(act, c)).astype(dt)
+        qstar = np.concatenate([q, attend(q)], axis=1)
+    return qstar[:, None, :]
+
+
+def gru_update(nodes, updates, kernel, recurrent_kernel, bias, act="tanh", rec_act="sigmoid"):
+    """``GRUUpdate.call``, kgcnn/layers/conv/mpnn_conv.py:183-200: one Keras GRUCell step (reset_after=True) with the node
+    values as state and the pooled messages as input; ``bias`` is Keras' ``(2, 3u)`` (input row, recurrent row)."""
+    h, x = np.asarray(nodes.values), np.asarray(updates.values)
+    dt = h.dtype
+    mx = np.matmul(x, kernel.astype(dt)) + (bias[0].astype(dt) if bias is not None else 0)
+    mh = np.matmul(h, recurrent_kernel.astype(dt)) + (bias[1].astype(dt) if bias is not None else 0)
+    xz, xr, xh = np.split(mx, 3, axis=1)
+    hz, hr, hh = np.split(mh, 3, axis=1)
+    z = activation(rec_act, xz + hz)
+    rg = activation(rec_act, xr + hr)
+    cand = activation(act, xh + rg * hh)
+    return R((z * h + (dt.type(1) - z) * cand).astype(dt), nodes.row_splits)
+
+
+def trafo_edge_net_messages(edges, kernel, bias, target_shape, act="linear"):
+    """``TrafoEdgeNetMessages.call``, mpnn_conv.py:44-57: Dense + reshape to ``(M, F', F)``."""
+    up = dense_values(edges.values, kernel, bias, act)
+    return R(up.reshape(up.shape[0], int(target_shape[0]), int(target_shape[1])), edges.row_splits)
+
+
+def matmul_messages(trafo, edges):
+    """``MatMulMessages.call``, mpnn_conv.py:88-103: ``batch_dot`` of per-edge matrices with per-edge vectors."""
+    return R(np.einsum("mrc,mc->mr", trafo.values, edges.values).astype(edges.values.dtype), edges.row_splits)
+
+
+def megnet_forward(weights, node_number, xyz, idx, env_number, nblocks=3, has_ff=True, use_set2set=True, gauss_args=None,
+                   set2set_args=None, act="kgcnn>softplus2", ff_act="kgcnn>softplus2",
+                   output_act=("kgcnn>softplus2", "kgcnn>softplus2", "linear"), ff_layers=2):
+    """``kgcnn.literature.Megnet.make_model`` forward, kgcnn/literature/Megnet.py:117-190, with the weights as the flat list
+    ``model.get_weights()`` gives (construction order: embeddings, feed-forward MLPs, blocks, readouts, output MLP)."""
+    gauss_args = gauss_args or {"bins": 20, "distance": 4, "offset": 0.0, "sigma": 0.4}
+    set2set_args = set2set_args or {"channels": 16, "T": 3, "pooling_method": "sum", "init_qstar": "0"}
+    w = iter(weights)
+    take = lambda k: [next(w) for _ in range(k)]
+
+    def take_mlp(n_layers, acts):
+        return [(next(w), next(w), a) for _, a in zip(range(n_layers), acts)]
+
+    emb_n, emb_u = take(2)
+    n = embedding(node_number, emb_n)
+    u = emb_u[np.asarray(env_number).astype(np.int32)]
+    pos1, pos2 = node_position(xyz, idx)
+    ed = gauss_basis(node_distance_euclidean(pos1, pos2), **gauss_args)
+
+    def ff_trio():
+        return [take_mlp(ff_layers, [ff_act] * ff_layers) for _ in range(3)]
+
+    def block_params():
+        p = {}
+        for name in ("phi_n", "phi_e", "phi_u"):                  # attribute order of MEGnetBlock
+            for suffix in ("", "_1", "_2"):
+                p["%s%s/kernel" % (name, suffix)], p["%s%s/bias" % (name, suffix)] = next(w), next(w)
+        return p
+
+    trio = ff_trio()
+    vp, ep, up = mlp(n, trio[0]), mlp(ed, trio[1]), mlp(u, trio[2])
+    vp2, ep2, up2 = vp, ep, up
+    for i in range(nblocks):
+        if has_ff and i > 0:
+            trio = ff_trio()
+            vp2, ep2, up2 = mlp(vp, trio[0]), mlp(ep, trio[1]), mlp(up, trio[2])
+        vp2, ep2, up2 = megnet_block(vp2, ep2, idx, up2, block_params(), act=act)
+        vp, ep, up = lazy_add([vp2, vp]), lazy_add([ep2, ep]), up2 + up
+    if use_set2set:
+        kv, bv, ke, be = take(4)
+        s2s = {k: set2set_args[k] for k in ("T", "pooling_method", "init_qstar")}
+        lk_v, _, lb_v = take(3)
+        lk_e, _, lb_e = take(3)
+        vs = pooling_set2set(dense(vp, kv, bv, "linear"), lk_v, lb_v, **s2s)
+        es = pooling_set2set(dense(ep, ke, be, "linear"), lk_e, lb_e, **s2s)
+    else:
+        vs, es = pooling_nodes(vp, "mean"), pooling_nodes(ep, "mean")
+    final = np.concatenate([vs.reshape(vs.shape[0], -1), es.reshape(es.shape[0], -1), up], axis=-1)
+    return mlp(final, take_mlp(len(output_act), output_act))
+
+
+def nmpn_forward(weights, node_number, edge_number, idx, depth=3, node_dim=64, set2set_args=None, edge_act="swish",
+                 edge_layers=3, output_act=("selu", "selu", "sigmoid"), output_bias=(True, True, False),
+                 pooling_method="sum"):
+    """``kgcnn.literature.NMPN.make_model`` forward (graph output, embedded node / edge numbers, Set2Set readout),
+    kgcnn/literature/NMPN.py:110-170, weights as the flat ``model.get_weights()`` list."""
+    set2set_args = set2set_args or {"channels": 32, "T": 3, "pooling_method": "sum", "init_qstar": "0"}
+    w = iter(weights)
+    emb_n, emb_e = next(w), next(w)
+    n0 = embedding(node_number, emb_n)
+    ed = embedding(edge_number, emb_e)
+    n = dense(n0, next(w), next(w), "linear")
+    nets = []
+    for _ in range(2):                                            # edge network "in", then "out"
+        layers = [(next(w), next(w), edge_act) for _ in range(edge_layers)]
+        nets.append(trafo_edge_net_messages(mlp(ed, layers), next(w), next(w), (node_dim, node_dim)))
+    gru_k, gru_r, gru_b = next(w), next(w), next(w)
+    for _ in range(depth):
+        m_in = matmul_messages(nets[0], gather_nodes_outgoing(n, idx))
+        m_out = matmul_messages(nets[1], gather_nodes_ingoing(n, idx))
+        eu = pooling_local_edges(n, lazy_concatenate([m_in, m_out], axis=-1), idx, pooling_method=pooling_method)
+        n = gru_update(n, eu, gru_k, gru_r, gru_b)
+    n = lazy_concatenate([n0, n], axis=-1)
+    out = dense(n, next(w), next(w), "linear")
+    lk, _, lb = next(w), next(w), next(w)
+    out = pooling_set2set(out, lk, lb, **{k: set2set_args[k] for k in ("T", "pooling_method", "init_qstar")})
+    out = out.reshape(out.shape[0], -1)
+    return mlp(out, [(next(w), next(w) if b else None, a) for a, b in zip(output_act, output_bias)])
 
 
 # ----------------------------------------------------------------------------------------

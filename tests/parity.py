@@ -36,9 +36,14 @@ def assert_rows_close(got, ref32, ref64=None, rtol=RTOL, floor=FLOOR, what=""):
     """Per-row bound against the float32 oracle; with the float64 twin given, additionally no row of the engine may be
     further from float64 truth than 4x the float32 oracle's own worst row (and never needs to beat 2e-6)."""
     err = rowwise_rel(got, ref32, floor)
-    assert err <= rtol, "%s: worst row off by %.3g relative (bar %.1g)" % (what, err, rtol)
+    bar = rtol
     if ref64 is not None:
         e_engine, e_oracle = rowwise_rel(got, ref64, floor), rowwise_rel(ref32, ref64, floor)
         assert e_engine <= max(4 * e_oracle, 2e-6), "%s: engine %.3g vs oracle %.3g from float64" % (
             what, e_engine, e_oracle)
+        # two float32 pipelines cannot agree better than the float32 oracle agrees with float64 truth: where the oracle
+        # itself is further than rtol / 2 from its twin (deep recurrent models with O(1) random weights), that distance is
+        # the noise floor of the comparison
+        bar = max(rtol, 2 * e_oracle)
+    assert err <= bar, "%s: worst row off by %.3g relative (bar %.1g)" % (what, err, bar)
     return err
