@@ -77,12 +77,15 @@ _SIGNATURES = {
     "mp_cfconv_fused_ws_f32": [P, c_int64, P, c_int, P, P, P, P, c_int64, c_int, P, P, c_size_t, P],
     "mp_cfconv_gauss_fused_ws_f32": [P, c_int64, P, c_int, c_float, c_float, c_float, P, P, P, P, c_int64, c_int, P, P,
                                      c_size_t, P],
+    "mp_cfconv_bwd_packed_floats": [],
+    "mp_cfconv_bwd_pack_f32": [P, P, c_int, P, P, P],
+    "mp_cfconv_gauss_dist_grad_f32": [P, P, c_int64, P, c_int, c_float, c_float, c_float, P, P, P, c_int64, c_int, P, P],
     "mp_cfconv_gauss_diag_f32": [P, c_int64, P, c_int, c_float, c_float, c_float, P, P, P, P, c_int64, P, P, P],
     "mp_painn_message_fused_f32": [P, P, c_int64, P, c_int, P, P, P, P, P, P, P, c_int64, P, P, P],
     "mp_lstm_zero_state_f32": [P, c_int64, c_int64, c_int, c_int, P, P],
     "mp_gru_combine_f32": [P, P, P, c_int64, c_int64, c_int, c_int, P, P],
     "mp_batched_matvec_f32": [P, P, c_int64, c_int64, c_int64, P, P],
-    "mp_painn_stage0_f32": [P, c_int64, P, c_int, c_float, P, P, P, c_int64, P, P, c_int64, P, P, c_int, c_float, c_int,
+    "mp_painn_stage0_f32": [P, c_int, c_int64, P, c_int, c_float, P, P, P, c_int64, P, P, c_int64, P, P, c_int, c_float, c_int,
                             c_float, P, P, P, P, P, P, P, P, P, P],
     "mp_painn_message_f32": [P, P, c_int64, P, c_int, P, P, P, P, P, P, P, c_int64, P, P, P, P],
     "mp_painn_message_bwd_f32": [P, P, c_int64, P, P, c_int, P, P, P, P, P, P, P, P, c_int64, P, P, P, P, P, P, c_int, P],
@@ -126,7 +129,7 @@ class SchnetForwardDesc(ctypes.Structure):
     _fields_ = ([("N", c_int64), ("M", c_int64), ("G", c_int64),
                  ("depth", ctypes.c_int32), ("vocab", ctypes.c_int32), ("flags", ctypes.c_int32),
                  ("bins", ctypes.c_int32),
-                 ("g_distance", c_float), ("g_sigma", c_float), ("g_offset", c_float), ("reserved_", c_float)]
+                 ("g_distance", c_float), ("g_sigma", c_float), ("g_offset", c_float), ("emb_dim", ctypes.c_int32)]
                 + [(name, c_void_p) for name in ("numbers", "xyz", "idx", "node_splits", "edge_splits", "embedding",
                                                  "W0", "b0")]
                 + [(name, c_void_p * MP_SCHNET_MAX_DEPTH) for name in ("Wx", "packed", "W2", "b2", "W3", "b3")]

@@ -110,7 +110,8 @@ __global__ __launch_bounds__(256) void painn_basis_kernel(PainnBasisArgs q) {
 }
 
 struct PainnNodeInit {
-  const float* numbers;  // (N) float node numbers (Keras Embedding casts to int32)
+  const void* numbers;   // (N) node numbers, float32 or int64 (Keras Embedding casts to int32)
+  int numbers_i64;
   const float* emb;      // (vocab, F)
   int vocab;
   int64_t N;
@@ -129,7 +130,8 @@ __global__ __launch_bounds__(256) void painn_stage0_kernel(PainnNodeInit ni, mp_
          t += static_cast<int64_t>(node_blocks) * 256) {
       const int64_t n = t / F;
       const int f = static_cast<int>(t % F);
-      const int zi = static_cast<int>(ni.numbers[n]);
+      const int zi = ni.numbers_i64 ? static_cast<int>(static_cast<const int64_t*>(ni.numbers)[n])
+                                    : static_cast<int>(static_cast<const float*>(ni.numbers)[n]);
       ni.z0[t] = (zi >= 0 && zi < ni.vocab) ? ni.emb[static_cast<int64_t>(zi) * F + f] : 0.0f;
       ni.v0[(n * 3 + 0) * F + f] = ni.v_init;
       ni.v0[(n * 3 + 1) * F + f] = ni.v_init;
@@ -579,7 +581,8 @@ __global__ __launch_bounds__(256) void painn_geometry_bwd_kernel(const float* __
 
 extern "C" {
 
-int mp_painn_stage0_f32(const float* numbers, int64_t N, const float* emb, int vocab, float v_init, float* z0, float* v0,
+int mp_painn_stage0_f32(const void* numbers, int numbers_i64, int64_t N, const float* emb, int vocab, float v_init,
+                        float* z0, float* v0,
                         const int64_t* idx, int64_t M, const int64_t* node_splits, const int64_t* edge_splits, int64_t G,
                         const float* xyz, const float* frequencies, int num_radial, float bessel_cutoff,
                         int envelope_exponent, float cos_cutoff, int32_t* recv, int32_t* send, int32_t* flags, float* dist,
@@ -593,7 +596,7 @@ int mp_painn_stage0_f32(const float* numbers, int64_t N, const float* emb, int v
   MP_REQUIRE(M == 0 || (idx && xyz && frequencies && recv && send && dist && rij && rbf),
              "mp_painn_stage0_f32: null edge pointer");
   MP_REQUIRE(cos_cutoff <= 0.0f || env != nullptr, "mp_painn_stage0_f32: envelope requested without a buffer");
-  PainnNodeInit ni{numbers, emb, vocab, N, v_init, z0, v0};
+  PainnNodeInit ni{numbers, numbers_i64, emb, vocab, N, v_init, z0, v0};
   mp_prep::EdgePrepArgs p{idx, M, node_splits, edge_splits, G, N, xyz, recv, send, dist, flags};
   PainnEdgeExtra ex{rij};
   const int node_blocks = static_cast<int>(mp::grid_for(N * F));

@@ -14,9 +14,9 @@ int mp_schnet_forward_launch(const mp_schnet_forward_desc* d, mpStream_t stream)
   MP_REQUIRE(d != nullptr, "mp_schnet_forward_launch: null descriptor");
   MP_REQUIRE(d->depth >= 1 && d->depth <= MP_SCHNET_MAX_DEPTH, "mp_schnet_forward_launch: depth %d not in 1..%d",
              d->depth, MP_SCHNET_MAX_DEPTH);
-  int rc = mp_schnet_stage0_f32(d->numbers, d->N, d->embedding, d->vocab, 64, d->W0, d->b0, d->Wx[0], d->n, d->x,
-                                d->idx, d->M, d->node_splits, d->edge_splits, d->G, d->xyz, d->recv, d->send, d->dist,
-                                d->flags_word, d->flags & 3, stream);
+  int rc = mp_schnet_stage0_f32(d->numbers, d->N, d->embedding, d->vocab, d->emb_dim == 128 ? 128 : 64, d->W0, d->b0,
+                                d->Wx[0], d->n, d->x, d->idx, d->M, d->node_splits, d->edge_splits, d->G, d->xyz,
+                                d->recv, d->send, d->dist, d->flags_word, d->flags & (3 | 256), stream);
   if (rc != MP_OK) return rc;
   for (int i = 0; i < d->depth; ++i) {
     rc = mp_cfconv_gauss_fused_f32(d->x, d->N, d->dist, d->bins, d->g_distance, d->g_sigma, d->g_offset, d->packed[i],

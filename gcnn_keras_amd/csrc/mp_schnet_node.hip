@@ -110,7 +110,8 @@ struct NodeArgs {
   int keep_agg;          // do not re-zero the consumed aggregation rows (layer API: the rows belong to the caller)
   float* n_out;          // UPD: updated node state (n itself is read only)
   // IN
-  const float* numbers;  // (N) float node numbers
+  const void* numbers;   // (N) node numbers: float32 (kgcnn/literature/Schnet.py:26) or int64 (the fork's force scripts)
+  int numbers_i64;
   const float* emb;      // (vocab, E)
   int vocab;
   const float* W0;       // (E, F)
@@ -180,7 +181,9 @@ __device__ __forceinline__ void schnet_node_body(const NodeArgs& a, int block, i
         const int64_t node = n0 + r;
         float v = 0.0f;
         if (t < a.ntiles && node < a.N) {
-          const int z = static_cast<int>(a.numbers[node]);  // Keras Embedding casts float input to int32
+          // Keras Embedding casts its input to int32
+          const int z = a.numbers_i64 ? static_cast<int>(static_cast<const int64_t*>(a.numbers)[node])
+                                      : static_cast<int>(static_cast<const float*>(a.numbers)[node]);
           if (z >= 0 && z < a.vocab) v = a.emb[static_cast<int64_t>(z) * E + k];
         }
         stg_in[j] = v;
@@ -390,10 +393,14 @@ __global__ __launch_bounds__(256) void schnet_readout_kernel(const float* __rest
                                                              const float* __restrict__ Wo1,
                                                              const float* __restrict__ bo1, float* __restrict__ out) {
   __shared__ float Ws[64 * 64];
-  for (int i = threadIdx.x; i < 64 * 64 / 4; i += 256)
-    reinterpret_cast<float4*>(Ws)[i] = reinterpret_cast<const float4*>(Wo0)[i];
+  // Wo0 == NULL: linear head - the model ends in last_mlp [.., 64, 1(linear)] + PoolingNodes(sum) without an output MLP
+  // (use_output_mlp=False, the fork's force configuration): out[g] = sum_n (h_n . Wo1 + bo1)
+  const bool linear_head = Wo0 == nullptr;
+  if (!linear_head)
+    for (int i = threadIdx.x; i < 64 * 64 / 4; i += 256)
+      reinterpret_cast<float4*>(Ws)[i] = reinterpret_cast<const float4*>(Wo0)[i];
   const int lane = threadIdx.x & 63;
-  const float b0v = bo0 ? bo0[lane] : 0.0f;
+  const float b0v = (!linear_head && bo0) ? bo0[lane] : 0.0f;
   const float w1v = Wo1[lane];
   const float b1v = bo1 ? bo1[0] : 0.0f;
   __syncthreads();
@@ -411,13 +418,16 @@ __global__ __launch_bounds__(256) void schnet_readout_kernel(const float* __rest
 #pragma unroll
       for (int u = 0; u < 8; ++u) pooled += (base + u < hi) ? v[u] : 0.0f;
     }
-    float y = 0.0f;
+    float y = pooled;
+    if (!linear_head) {
+      y = 0.0f;
 #pragma unroll
-    for (int k = 0; k < 64; ++k) y = fmaf(__int_as_float(__builtin_amdgcn_readlane(__float_as_int(pooled), k)), Ws[k * 64 + lane], y);
-    y = ssp_exact(y + b0v);
+      for (int k = 0; k < 64; ++k) y = fmaf(__int_as_float(__builtin_amdgcn_readlane(__float_as_int(pooled), k)), Ws[k * 64 + lane], y);
+      y = ssp_exact(y + b0v);
+    }
     float o = y * w1v;
     for (int off = 32; off > 0; off >>= 1) o += __shfl_xor(o, off, 64);
-    if (lane == 0) out[g] = o + b1v;
+    if (lane == 0) out[g] = o + (linear_head ? static_cast<float>(hi - lo) * b1v : b1v);
   }
 }
 
@@ -462,6 +472,17 @@ int launch_node(const NodeArgs& a, int flags, hipStream_t s, const char* what) {
                      : launch_node_impl<MODE, E, false, false>(a, s, what);
 }
 
+template <int E>
+void launch_stage0(const NodeArgs& a, const mp_prep::EdgePrepArgs& p, int node_blocks, unsigned grid, int flags_arg,
+                   hipStream_t s) {
+  switch (flags_arg & 3) {
+    case 0: schnet_stage0_kernel<E, false, true, false><<<grid, 256, 0, s>>>(a, p, node_blocks); break;
+    case 1: schnet_stage0_kernel<E, true, true, false><<<grid, 256, 0, s>>>(a, p, node_blocks); break;
+    case 2: schnet_stage0_kernel<E, false, true, true><<<grid, 256, 0, s>>>(a, p, node_blocks); break;
+    default: schnet_stage0_kernel<E, true, true, true><<<grid, 256, 0, s>>>(a, p, node_blocks); break;
+  }
+}
+
 }  // namespace
 
 extern "C" {
@@ -475,15 +496,19 @@ int mp_debug_node_diag(unsigned long long* out8_host) {  // diagnostic build onl
 }
 #endif
 
+// flags bit 8 (value 256): `numbers` points to int64 node numbers instead of float32
 int mp_schnet_node_in_f32(const float* numbers, int64_t N, const float* emb, int vocab, int emb_dim, const float* W0,
                           const float* b0, const float* Wx, float* n_out, float* x_out, int flags, mpStream_t stream) {
   MP_REQUIRE(N >= 0 && vocab >= 1, "mp_schnet_node_in_f32: bad sizes");
-  MP_REQUIRE(emb_dim == 64, "mp_schnet_node_in_f32: built for embedding width 64 (got %d)", emb_dim);
+  MP_REQUIRE(emb_dim == 64 || emb_dim == 128, "mp_schnet_node_in_f32: built for embedding width 64 or 128 (got %d)",
+             emb_dim);
   if (N == 0) return MP_OK;
   MP_REQUIRE(numbers && emb && W0 && Wx && n_out && x_out, "mp_schnet_node_in_f32: null pointer");
   NodeArgs a{};
   a.N = N;
-  a.numbers = numbers; a.emb = emb; a.vocab = vocab; a.W0 = W0; a.b0 = b0; a.Wx = Wx; a.n = n_out; a.x = x_out;
+  a.numbers = numbers; a.numbers_i64 = (flags & 256) ? 1 : 0;
+  a.emb = emb; a.vocab = vocab; a.W0 = W0; a.b0 = b0; a.Wx = Wx; a.n = n_out; a.x = x_out;
+  if (emb_dim == 128) return launch_node<NODE_IN, 128>(a, flags, mp::as_stream(stream), "mp_schnet_node_in_f32");
   return launch_node<NODE_IN, 64>(a, flags, mp::as_stream(stream), "mp_schnet_node_in_f32");
 }
 
@@ -492,7 +517,8 @@ int mp_schnet_stage0_f32(const float* numbers, int64_t N, const float* emb, int 
                          const int64_t* node_splits, const int64_t* edge_splits, int64_t G, const float* xyz,
                          int32_t* recv, int32_t* send, float* dist, int32_t* flags, int flags_arg, mpStream_t stream) {
   MP_REQUIRE(N >= 0 && M >= 0 && G >= 0 && vocab >= 1, "mp_schnet_stage0_f32: bad sizes");
-  MP_REQUIRE(emb_dim == 64, "mp_schnet_stage0_f32: built for embedding width 64 (got %d)", emb_dim);
+  MP_REQUIRE(emb_dim == 64 || emb_dim == 128, "mp_schnet_stage0_f32: built for embedding width 64 or 128 (got %d)",
+             emb_dim);
   MP_REQUIRE(N < (int64_t{1} << 31) && M < (int64_t{1} << 31), "mp_schnet_stage0_f32: N, M must fit int32");
   const int64_t tiles16 = (N + 15) / 16;
   if (N == 0 || M == 0 || tiles16 > 1024 || G > mp_prep::PREP_LDS_GRAPHS) {
@@ -506,18 +532,15 @@ int mp_schnet_stage0_f32(const float* numbers, int64_t N, const float* emb, int 
   MP_REQUIRE((dist == nullptr) || (xyz != nullptr), "mp_schnet_stage0_f32: dist requested without coordinates");
   NodeArgs a{};
   a.N = N; a.ntiles = static_cast<int>(tiles16);
-  a.numbers = numbers; a.emb = emb; a.vocab = vocab; a.W0 = W0; a.b0 = b0; a.Wx = Wx; a.n = n_out; a.x = x_out;
+  a.numbers = numbers; a.numbers_i64 = (flags_arg & 256) ? 1 : 0;
+  a.emb = emb; a.vocab = vocab; a.W0 = W0; a.b0 = b0; a.Wx = Wx; a.n = n_out; a.x = x_out;
   mp_prep::EdgePrepArgs p{idx, M, node_splits, edge_splits, G, N, xyz, recv, send, dist, flags};
   const int node_blocks = a.ntiles;
   const int edge_blocks = static_cast<int>(mp::grid_for(M));
   hipStream_t s = mp::as_stream(stream);
   const unsigned grid = static_cast<unsigned>(node_blocks + edge_blocks);
-  switch (flags_arg & 3) {
-    case 0: schnet_stage0_kernel<64, false, true, false><<<grid, 256, 0, s>>>(a, p, node_blocks); break;
-    case 1: schnet_stage0_kernel<64, true, true, false><<<grid, 256, 0, s>>>(a, p, node_blocks); break;
-    case 2: schnet_stage0_kernel<64, false, true, true><<<grid, 256, 0, s>>>(a, p, node_blocks); break;
-    default: schnet_stage0_kernel<64, true, true, true><<<grid, 256, 0, s>>>(a, p, node_blocks); break;
-  }
+  if (emb_dim == 128) launch_stage0<128>(a, p, node_blocks, grid, flags_arg, s);
+  else launch_stage0<64>(a, p, node_blocks, grid, flags_arg, s);
   return mp::check_launch("mp_schnet_stage0_f32");
 }
 
@@ -570,7 +593,7 @@ int mp_schnet_readout_f32(const float* h, const int64_t* node_splits, int64_t G,
                           const float* Wo1, const float* bo1, float* out, mpStream_t stream) {
   MP_REQUIRE(G >= 0, "mp_schnet_readout_f32: bad sizes");
   if (G == 0) return MP_OK;
-  MP_REQUIRE(h && node_splits && Wo0 && Wo1 && out, "mp_schnet_readout_f32: null pointer");
+  MP_REQUIRE(h && node_splits && Wo1 && out, "mp_schnet_readout_f32: null pointer");
   schnet_readout_kernel<<<static_cast<unsigned>(mp::ceil_div(G, 4) < 1024 ? mp::ceil_div(G, 4) : 1024), 256, 0,
                           mp::as_stream(stream)>>>(h, node_splits, G, Wo0, bo0, Wo1,
                                                                                   bo1, out);

@@ -24,26 +24,44 @@ def _as_list(v, n):
     return list(v) if isinstance(v, (list, tuple)) else [v] * n
 
 
+def head_of(config):
+    """Which readout a configuration ends in: ``"mlp"`` = the reference default (last_mlp [128, 64], PoolingNodes(sum),
+    output_mlp [64, 1] with (ssp, linear)); ``"linear"`` = the fork's force configuration (force_schnet.py:139-156:
+    last_mlp [128, 64, 1] with (ssp, ssp, linear), PoolingNodes(sum), no output MLP); ``None`` = neither."""
+    lm = config["last_mlp"]
+    units = _as_list(lm["units"], 1)
+    acts = _as_list(lm.get("activation"), len(units))
+    if not all(_as_list(lm.get("use_bias", True), len(units))):
+        return None
+    if config.get("use_output_mlp", True):
+        om = config["output_mlp"]
+        if (units == [128, 64] and all(a in _SSP for a in acts) and _as_list(om["units"], 1) == [64, 1]
+                and _as_list(om.get("activation"), 2)[0] in _SSP and _as_list(om.get("activation"), 2)[1] in ("linear", None)
+                and all(_as_list(om.get("use_bias", True), 2))):
+            return "mlp"
+        return None
+    if units == [128, 64, 1] and all(a in _SSP for a in acts[:2]) and acts[2] in ("linear", None):
+        return "linear"
+    return None
+
+
 def supports(config):
     """True if a ``Schnet.make_model`` configuration (the merged keyword dictionary) maps onto the fused kernels:
-    float node numbers through a 64-wide embedding, distances and Gauss basis made inside the model, 128 units with
-    shifted softplus and sum pooling, ``last_mlp`` [128, 64] / ``output_mlp`` [64, 1], graph output.  Anything else
-    runs the layer path (kgcnn/literature/Schnet.py:104-148 op by op)."""
+    node numbers (float32 or int64) through a 64- or 128-wide embedding, distances and Gauss basis made inside the
+    model, 128 units with shifted softplus and sum pooling, graph output through one of the two heads of ``head_of``.
+    Anything else runs the layer path (kgcnn/literature/Schnet.py:104-148 op by op)."""
     try:
-        ia, lm, om = config["interaction_args"], config["last_mlp"], config["output_mlp"]
+        ia = config["interaction_args"]
         inputs = config.get("inputs")
         if inputs is not None and (len(inputs[0]["shape"]) != 1 or tuple(inputs[1]["shape"])[-1] != 3):
             return False
         return bool(
             config.get("make_distance", True) and config.get("expand_distance", True)
-            and config.get("use_output_mlp", True) and config.get("output_embedding", "graph") == "graph"
+            and config.get("output_embedding", "graph") == "graph"
             and ia.get("units") == 128 and ia.get("cfconv_pool", "sum") in _SUM
             and ia.get("activation", _SSP[0]) in _SSP and ia.get("use_bias", True) is True
-            and config["input_embedding"]["node"]["output_dim"] == 64
-            and _as_list(lm["units"], 1) == [128, 64] and _as_list(lm.get("activation"), 2) in ([_SSP[0]] * 2, [_SSP[1]] * 2)
-            and all(_as_list(lm.get("use_bias", True), 2))
-            and _as_list(om["units"], 1) == [64, 1] and _as_list(om.get("activation"), 2)[0] in _SSP
-            and _as_list(om.get("activation"), 2)[1] in ("linear", None) and all(_as_list(om.get("use_bias", True), 2))
+            and config["input_embedding"]["node"]["output_dim"] in (64, 128)
+            and head_of(config) is not None
             and config["node_pooling_args"].get("pooling_method") in _SUM
             and 1 <= int(config["gauss_args"]["bins"]) <= 32 and float(config["gauss_args"]["sigma"]) != 0.0
             and int(config["depth"]) >= 1)
@@ -99,8 +117,12 @@ class FusedSchnet:
         self.use_graph = use_graph
         self.p = {k: (v if torch.is_tensor(v) else torch.from_numpy(np.ascontiguousarray(v, dtype=np.float32)).cuda())
                   for k, v in params.items() if v is not None}
-        if tuple(self.p["embedding"].shape)[1] != 64 or tuple(self.p["dense0/kernel"].shape) != (64, 128):
-            raise ValueError("FusedSchnet is built for embedding width 64 and 128 units")
+        self.emb_dim = int(self.p["embedding"].shape[1])
+        if self.emb_dim not in (64, 128) or tuple(self.p["dense0/kernel"].shape) != (self.emb_dim, 128):
+            raise ValueError("FusedSchnet is built for embedding width 64 / 128 and 128 units")
+        # head: output MLP [64, 1] after the pooling (reference default) or last_mlp's own third layer Dense(1, linear)
+        # before it (use_output_mlp=False: the fork's force_schnet.py configuration)
+        self.linear_head = "output_mlp/0/kernel" not in self.p
         # filter-MLP weights of every block in the cfconv kernel's LDS image order (packed once per weight update)
         images = packed if packed is not None else pack_weights(self.p, depth, int(self.gauss["bins"]))
         self.packed, self.node_images = images["cfconv"], images["node"]
@@ -116,6 +138,8 @@ class FusedSchnet:
         packer, on-GPU SetRange) already established it - otherwise one index pass runs and its flag word is read back
         (the only host synchronisation of a batch's life, on the current stream only)."""
         self._b, self.N, self.M, self.G = b, n, m, g
+        i64 = 256 if b["z"].dtype == torch.int64 else 0      # flags bit 8: int64 node numbers (the fork's input dtype)
+        self.node_flags = (self.flags_arg & 3) | i64
         dev = "cuda"
         self.recv = torch.empty(max(m, 1), dtype=torch.int32, device=dev)
         self.send = torch.empty(max(m, 1), dtype=torch.int32, device=dev)
@@ -173,19 +197,19 @@ class FusedSchnet:
         if self.sorted or self.M == 0:
             # stage 0: node-input chain and edge preparation in one launch (independent work on disjoint workgroups)
             _ffi.call("mp_schnet_stage0_f32", _ffi.ptr(b["z"]), self.N, _ffi.ptr(p["embedding"]),
-                      int(p["embedding"].shape[0]), 64, _ffi.ptr(w["dense0/kernel"]), _ffi.ptr(p.get("dense0/bias")),
+                      int(p["embedding"].shape[0]), self.emb_dim, _ffi.ptr(w["dense0/kernel"]), _ffi.ptr(p.get("dense0/bias")),
                       _ffi.ptr(w["interaction0/dense1/kernel"]), _ffi.ptr(self.n), _ffi.ptr(self.x),
                       _ffi.ptr(b["idx"]), self.M, _ffi.ptr(b["ns"]), _ffi.ptr(b["es"]), self.G, _ffi.ptr(b["xyz"]),
                       _ffi.ptr(self.recv), _ffi.ptr(self.send), _ffi.ptr(self.dist), _ffi.ptr(self.flags),
-                      self.flags_arg & 3, _ffi.stream())
+                      self.node_flags, _ffi.stream())
         else:
             self._prepare()
             _ffi.call("mp_sort_segments_i32", _ffi.ptr(self.recv), self.M, _ffi.ptr(self.recv_sorted),
                       _ffi.ptr(self.perm), _ffi.ptr(self.sort_ws), self.sort_ws_bytes, _ffi.stream())
             _ffi.call("mp_schnet_node_in_f32", _ffi.ptr(b["z"]), self.N, _ffi.ptr(p["embedding"]),
-                      int(p["embedding"].shape[0]), 64, _ffi.ptr(w["dense0/kernel"]), _ffi.ptr(p.get("dense0/bias")),
+                      int(p["embedding"].shape[0]), self.emb_dim, _ffi.ptr(w["dense0/kernel"]), _ffi.ptr(p.get("dense0/bias")),
                       _ffi.ptr(w["interaction0/dense1/kernel"]), _ffi.ptr(self.n), _ffi.ptr(self.x),
-                      self.flags_arg & 3, _ffi.stream())
+                      self.node_flags, _ffi.stream())
         for i in range(self.depth):
             pre = "interaction%d/" % i
             self._cfconv(i, self.agg)
@@ -193,18 +217,24 @@ class FusedSchnet:
                 _ffi.call("mp_schnet_node_update_f32", _ffi.ptr(self.agg), self.N, _ffi.ptr(w[pre + "dense2/kernel"]),
                           _ffi.ptr(p.get(pre + "dense2/bias")), _ffi.ptr(w[pre + "dense3/kernel"]),
                           _ffi.ptr(p.get(pre + "dense3/bias")), _ffi.ptr(self.n),
-                          _ffi.ptr(w["interaction%d/dense1/kernel" % (i + 1)]), _ffi.ptr(self.x), self.flags_arg & 3,
+                          _ffi.ptr(w["interaction%d/dense1/kernel" % (i + 1)]), _ffi.ptr(self.x), self.node_flags,
                           _ffi.stream())
             else:
                 _ffi.call("mp_schnet_node_last_f32", _ffi.ptr(self.agg), self.N, _ffi.ptr(w[pre + "dense2/kernel"]),
                           _ffi.ptr(p.get(pre + "dense2/bias")), _ffi.ptr(w[pre + "dense3/kernel"]),
                           _ffi.ptr(p.get(pre + "dense3/bias")), _ffi.ptr(self.n), _ffi.ptr(w["last_mlp/0/kernel"]),
                           _ffi.ptr(p.get("last_mlp/0/bias")), _ffi.ptr(w["last_mlp/1/kernel"]),
-                          _ffi.ptr(p.get("last_mlp/1/bias")), _ffi.ptr(self.h), self.flags_arg & 3, _ffi.stream())
-        _ffi.call("mp_schnet_readout_f32", _ffi.ptr(self.h), _ffi.ptr(b["ns"]), self.G,
-                  _ffi.ptr(p["output_mlp/0/kernel"]), _ffi.ptr(p.get("output_mlp/0/bias")),
-                  _ffi.ptr(p["output_mlp/1/kernel"]), _ffi.ptr(p.get("output_mlp/1/bias")), _ffi.ptr(self.out),
-                  _ffi.stream())
+                          _ffi.ptr(p.get("last_mlp/1/bias")), _ffi.ptr(self.h), self.node_flags, _ffi.stream())
+        wo0, bo0, wo1, bo1 = self._head()
+        _ffi.call("mp_schnet_readout_f32", _ffi.ptr(self.h), _ffi.ptr(b["ns"]), self.G, _ffi.ptr(wo0), _ffi.ptr(bo0),
+                  _ffi.ptr(wo1), _ffi.ptr(bo1), _ffi.ptr(self.out), _ffi.stream())
+
+    def _head(self):
+        p = self.p
+        if self.linear_head:
+            return None, None, p["last_mlp/2/kernel"], p.get("last_mlp/2/bias")
+        return (p["output_mlp/0/kernel"], p.get("output_mlp/0/bias"), p["output_mlp/1/kernel"],
+                p.get("output_mlp/1/bias"))
 
     # ------------------------------------------------------------------------------------------------ current stream
     def _capture(self):
@@ -282,7 +312,8 @@ class FusedSchnet:
         p, b, ga, w = self.p, self._b, self.gauss, self.node_images
         d = _ffi.SchnetForwardDesc()
         d.N, d.M, d.G = self.N, self.M, self.G
-        d.depth, d.vocab, d.flags, d.bins = self.depth, int(p["embedding"].shape[0]), self.flags_arg, int(ga["bins"])
+        d.depth, d.vocab, d.bins = self.depth, int(p["embedding"].shape[0]), int(ga["bins"])
+        d.flags = self.flags_arg | (self.node_flags & 256)
         d.g_distance, d.g_sigma, d.g_offset = float(ga["distance"]), float(ga["sigma"]), float(ga["offset"])
         addr = lambda t: None if t is None else t.data_ptr()
         d.numbers, d.xyz, d.idx = addr(b["z"]), addr(b["xyz"]), addr(b["idx"])
@@ -295,8 +326,9 @@ class FusedSchnet:
             d.W3[i], d.b3[i] = addr(w[pre + "dense3/kernel"]), addr(p.get(pre + "dense3/bias"))
         d.Wl0, d.bl0 = addr(w["last_mlp/0/kernel"]), addr(p.get("last_mlp/0/bias"))
         d.Wl1, d.bl1 = addr(w["last_mlp/1/kernel"]), addr(p.get("last_mlp/1/bias"))
-        d.Wo0, d.bo0 = addr(p["output_mlp/0/kernel"]), addr(p.get("output_mlp/0/bias"))
-        d.Wo1, d.bo1 = addr(p["output_mlp/1/kernel"]), addr(p.get("output_mlp/1/bias"))
+        wo0, bo0, wo1, bo1 = self._head()
+        d.Wo0, d.bo0, d.Wo1, d.bo1 = addr(wo0), addr(bo0), addr(wo1), addr(bo1)
+        d.emb_dim = self.emb_dim
         d.recv, d.send, d.dist, d.flags_word = addr(self.recv), addr(self.send), addr(self.dist), addr(self.flags)
         d.n, d.x, d.agg, d.h, d.out = addr(self.n), addr(self.x), addr(self.agg), addr(self.h), addr(self.out)
         return d
@@ -374,25 +406,28 @@ class SchnetFusedRoute:
         self.mode = "auto"          # auto: direct launch on first sight, graph replay afterwards | graph | direct | eager
         self.copy_output = True
         self._slots = {}
+        self._gslots = {}           # batch slots of the energy + force pass (fused_schnet_force.FusedSchnetForce)
         self._p = None
         self._wkey = None
         self._packed = None
+        self._grad_images = None    # transposed kernels / cfconv reverse images, built on the first force call
+        self.single_state = True    # SchNet heads the route accepts end in one energy value per graph
         self.last = None            # how the last call ran: "direct" | "graph" | "eager"
 
     # -- applicability of one call -----------------------------------------------------------------------------------
     @staticmethod
-    def accepts(inputs):
+    def accepts(inputs, with_forces=False):
         from .autograd import needs_grad
         from .ragged import RaggedTensor
         if not (isinstance(inputs, (list, tuple)) and len(inputs) == 3
                 and all(isinstance(x, RaggedTensor) for x in inputs)):
             return False
         z, xyz, idx = (x.values for x in inputs)
-        return (z.is_cuda and z.dtype == torch.float32 and z.dim() == 1 and xyz.dtype == torch.float32
+        return (z.is_cuda and z.dtype in (torch.float32, torch.int64) and z.dim() == 1 and xyz.dtype == torch.float32
                 and xyz.dim() == 2 and int(xyz.shape[1]) == 3 and idx.dtype == torch.int64 and idx.dim() == 2
                 and int(idx.shape[1]) == 2 and z.is_contiguous() and xyz.is_contiguous() and idx.is_contiguous()
                 and int(xyz.shape[0]) == int(z.shape[0]) and inputs[0].nrows() == inputs[2].nrows()
-                and not needs_grad(z, xyz))
+                and (with_forces or not needs_grad(z, xyz)))
 
     # -- weights ------------------------------------------------------------------------------------------------------
     def _sync_weights(self):
@@ -404,10 +439,16 @@ class SchnetFusedRoute:
         torch.cuda.synchronize()   # forwards in flight still read the old images
         if moved:                  # other tensors: every bound slot (descriptor, graph) points at the old ones
             self._slots.clear()
+            self._gslots.clear()
+            self._grad_images = None
             self._p = {k: v for k, v in p.items() if v is not None}
             self._packed = pack_weights(self._p, self.depth, int(self.gauss["bins"]))
         else:                      # same tensors, new values: re-fill the images the graphs already point at
             pack_weights(self._p, self.depth, int(self.gauss["bins"]), out=self._packed)
+            if self._grad_images is not None:
+                from .fused_schnet_force import make_grad_images
+                make_grad_images(self._p, self.depth, int(self.gauss["bins"]), "output_mlp/0/kernel" not in self._p,
+                                 out=self._grad_images)
         self._wkey = key
 
     # -- batch slots --------------------------------------------------------------------------------------------------
@@ -450,14 +491,45 @@ class SchnetFusedRoute:
         self.last = how
         return out.clone() if self.copy_output else out
 
+    def energy_force(self, inputs):
+        """``(energy (G', 1), force (N, 3))`` with force = -dE/dx: fused forward + hand-written reverse pass, one HIP
+        graph per bound batch (gcnn_keras_amd/fused_schnet_force.py)."""
+        from .fused_schnet_force import FusedSchnetForce, make_grad_images
+        node, xyz, idx = inputs
+        self._sync_weights()
+        if self._grad_images is None:
+            self._grad_images = make_grad_images(self._p, self.depth, int(self.gauss["bins"]),
+                                                 "output_mlp/0/kernel" not in self._p)
+        key = self._key(node, xyz, idx)
+        slot = self._gslots.get(key)
+        if slot is None:
+            slot = FusedSchnetForce(self._p, self._packed, self._grad_images, self.depth, self.gauss,
+                                    fast_softplus=self.fast_softplus)
+            slot.bind(node, xyz, idx)
+            while len(self._gslots) >= self.max_slots:
+                self._gslots.pop(next(iter(self._gslots)))
+            self._gslots[key] = slot
+        elif next(reversed(self._gslots)) != key:
+            self._gslots[key] = self._gslots.pop(key)
+        slot.calls += 1
+        how = self.mode
+        if how == "auto":
+            how = "eager" if slot.calls == 1 else "graph"
+        elif how == "direct":
+            how = "eager"
+        self.last = how
+        eng, force = slot.run_current(how)
+        return (eng.clone(), force.clone()) if self.copy_output else (eng, force)
+
     def slot_of(self, inputs):
         return self._slots.get(self._key(*inputs))
 
     def check_flags(self):
-        for slot in self._slots.values():
+        for slot in list(self._slots.values()) + list(self._gslots.values()):
             slot.check_flags()
 
     def release(self):
         """Unbind every batch (frees the work buffers and the references to the input tensors)."""
         torch.cuda.synchronize()
         self._slots.clear()
+        self._gslots.clear()

@@ -159,7 +159,8 @@ class FusedPainn:
     def _forward(self):
         p, w, n, m = self.p, self.w, self.N, self.M
         node, xyz, idx = self.inputs
-        _ffi.call("mp_painn_stage0_f32", _ffi.ptr(node.values), n, _ffi.ptr(p["embedding"]),
+        _ffi.call("mp_painn_stage0_f32", _ffi.ptr(node.values), 1 if node.values.dtype == torch.int64 else 0, n,
+                  _ffi.ptr(p["embedding"]),
                   int(p["embedding"].shape[0]), self.v_init, _ffi.ptr(self.z0), _ffi.ptr(self.v0), _ffi.ptr(idx.values), m,
                   _ffi.ptr(node.row_splits), _ffi.ptr(idx.row_splits), self.G, _ffi.ptr(xyz.values),
                   _ffi.ptr(p["bessel/frequencies"]), self.B, float(self.cfg["bessel_basis"]["cutoff"]),
@@ -311,7 +312,7 @@ class PainnFusedRoute:
                 and all(isinstance(x, RaggedTensor) for x in inputs)):
             return False
         z, xyz, idx = (x.values for x in inputs)
-        return (z.is_cuda and z.dtype == torch.float32 and z.dim() == 1 and xyz.dtype == torch.float32
+        return (z.is_cuda and z.dtype in (torch.float32, torch.int64) and z.dim() == 1 and xyz.dtype == torch.float32
                 and xyz.dim() == 2 and int(xyz.shape[1]) == 3 and idx.dtype == torch.int64 and idx.dim() == 2
                 and int(idx.shape[1]) == 2 and z.is_contiguous() and xyz.is_contiguous() and idx.is_contiguous()
                 and int(xyz.shape[0]) == int(z.shape[0]) and inputs[0].nrows() == inputs[2].nrows()

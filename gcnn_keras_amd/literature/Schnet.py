@@ -126,7 +126,7 @@ def make_model(inputs: list = None, input_embedding: dict = None, make_distance:
             p[pre + "dense2/kernel"], p[pre + "dense2/bias"] = inter.lay_dense2.kernel, inter.lay_dense2.bias
             p[pre + "dense3/kernel"], p[pre + "dense3/bias"] = inter.lay_dense3.kernel, inter.lay_dense3.bias
         for name, mlp in (("last_mlp", last), ("output_mlp", out_mlp)):
-            for k, d in enumerate(mlp.mlp_dense_layer_list):
+            for k, d in enumerate(mlp.mlp_dense_layer_list if mlp is not None else []):
                 p["%s/%d/kernel" % (name, k)], p["%s/%d/bias" % (name, k)] = d.kernel, d.bias
         return p
 

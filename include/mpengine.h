@@ -254,6 +254,18 @@ int mp_cfconv_gauss_fused_ws_f32(const float* x, int64_t N, const float* dist, i
                                  const int32_t* perm, int64_t M, int flags, float* out_zeroed, void* ws, size_t ws_bytes,
                                  mpStream_t stream);
 
+/* Reverse pass of SchNetCFconv for forces (kgcnn/model/force.py:159-177 through schnet_conv.py:73-79, geom.py:567-571).
+ * dE/dx_j is the forward kernel itself with the two index columns swapped (g_out in place of x, the sender-sorted list in
+ * place of the receiver-sorted one).  mp_cfconv_gauss_dist_grad_f32 is the other half: per edge (original order)
+ *   g_d[e] (+)= sum_h (v_e W2^T)_h * ssp'(g(d_e) W1 + b1)_h * (g'(d_e) W1)_h ,  v_e = g_out[recv[e]] * x[send[e]]
+ * with the weights in the image of mp_cfconv_bwd_pack_f32 (mp_cfconv_bwd_packed_floats() floats: W1 | b1 as the forward
+ * packs them, W2 re-ordered for the A operand).  Same FP32 MFMA tiles as the forward (three chains per 32-edge tile). */
+int mp_cfconv_bwd_packed_floats(void);
+int mp_cfconv_bwd_pack_f32(const float* W1, const float* b1, int B, const float* W2, float* packed, mpStream_t stream);
+int mp_cfconv_gauss_dist_grad_f32(const float* x, const float* g_out, int64_t N, const float* dist, int bins,
+                                  float distance, float sigma, float offset, const float* packed_bwd, const int32_t* recv,
+                                  const int32_t* send, int64_t M, int accumulate, float* g_d, mpStream_t stream);
+
 /* Diagnostic build of mp_cfconv_gauss_fused_f32 (20 bins, fast softplus): adds per-phase shader-cycle sums into
  * diag8 (8 x uint64, caller-zeroed): [0] weight staging, [1] tile setup + Gauss basis, [2] GEMM1, [3] softplus +
  * sender-row loads issued, [4] GEMM2, [5] multiply + slab write, [6] slab read, [7] segmented sum + stores/atomics.
@@ -292,7 +304,8 @@ int mp_batched_matvec_f32(const float* mat, const float* vec, int64_t M, int64_t
  * bits), NodePosition -> EdgeDirectionNormalized (rij (M,3), geom.py:331-378) -> NodeDistanceEuclidean (dist (M)) ->
  * BesselBasisLayer (rbf (M,B), geom.py:772-785) and, if rbfd != NULL, d rbf / d dist (M,B) for the reverse pass;
  * cos_cutoff > 0 adds CosCutOffEnvelope (env (M), geom.py:831-837) and its derivative envd (nullable). */
-int mp_painn_stage0_f32(const float* numbers, int64_t N, const float* emb, int vocab, float v_init, float* z0, float* v0,
+int mp_painn_stage0_f32(const void* numbers /* float32, or int64 if numbers_i64 */, int numbers_i64, int64_t N,
+                        const float* emb, int vocab, float v_init, float* z0, float* v0,
                         const int64_t* idx, int64_t M, const int64_t* node_splits, const int64_t* edge_splits, int64_t G,
                         const float* xyz, const float* frequencies, int num_radial, float bessel_cutoff,
                         int envelope_exponent, float cos_cutoff, int32_t* recv, int32_t* send, int32_t* flags, float* dist,
@@ -337,7 +350,11 @@ int mp_edge_geometry_bwd_f32(const float* g_d, const float* g_rij, int slices, c
  * node_in:     n = Embedding(Z) W0 + b0 ; x = n Wx
  * node_update: n += ssp(agg W2 + b2) W3 + b3 ; x = n Wx_next ; agg := 0
  * node_last:   n' = n + ssp(agg W2 + b2) W3 + b3 ; h = ssp(ssp(n' Wl0 + bl0) Wl1 + bl1) (N,64) ; agg := 0
- * readout:     out[g] = ssp(sum_{nodes of g} h W_o0 + b_o0) W_o1 + b_o1   (PoolingNodes(sum) + MLP([64,1]))
+ * readout:     out[g] = ssp(sum_{nodes of g} h W_o0 + b_o0) W_o1 + b_o1   (PoolingNodes(sum) + MLP([64,1]));
+ *              W_o0 == NULL: out[g] = sum_{nodes of g} (h W_o1 + b_o1)  (last_mlp ending in Dense(1, linear), then
+ *              PoolingNodes(sum), use_output_mlp=False: the fork's force_schnet.py configuration)
+ * The embedding width is 64 or 128; flags bit 8 (256): `numbers` holds int64 node numbers (the fork's scripts declare
+ * int64 inputs) instead of float32.
  * flags bit0: fast softplus as in mp_cfconv_fused_f32; bit1: every weight-matrix pointer is an
  * mp_schnet_node_pack_f32 image of the Keras kernel instead of the kernel itself (biases stay plain): the image stores,
  * per wave and lane, the registers of four consecutive k-steps as one float4, so a workgroup loads its weight slices
@@ -404,8 +421,9 @@ int mp_cos_cutoff_grad_f32(const float* d, int64_t n, float cutoff, const float*
 typedef struct mp_schnet_forward_desc {
   int64_t N, M, G;
   int32_t depth, vocab, flags, bins;
-  float g_distance, g_sigma, g_offset, reserved_;
-  const float* numbers;            /* (N) float node numbers */
+  float g_distance, g_sigma, g_offset;
+  int32_t emb_dim;                 /* embedding width: 64 (0 = 64) or 128 */
+  const float* numbers;            /* (N) node numbers: float32, or int64 with flags bit 8 */
   const float* xyz;                /* (N,3) */
   const int64_t* idx;              /* (M,2) sample indices */
   const int64_t* node_splits;      /* (G+1) */
@@ -420,7 +438,7 @@ typedef struct mp_schnet_forward_desc {
   const float* W3[MP_SCHNET_MAX_DEPTH];
   const float* b3[MP_SCHNET_MAX_DEPTH];
   const float* Wl0; const float* bl0; const float* Wl1; const float* bl1;   /* last_mlp */
-  const float* Wo0; const float* bo0; const float* Wo1; const float* bo1;   /* output_mlp */
+  const float* Wo0; const float* bo0; const float* Wo1; const float* bo1;   /* output_mlp; Wo0 == NULL: linear head Wo1 */
   int32_t* recv; int32_t* send; float* dist; int32_t* flags_word;           /* (M) work buffers, flag word */
   float* n; float* x; float* agg; float* h; float* out;                     /* (N,128) x3 [agg zeroed], (N,64), (G,1) */
 } mp_schnet_forward_desc;

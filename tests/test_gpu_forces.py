@@ -189,3 +189,104 @@ def test_energy_force_model_esp_branch():
     plain = EnergyForceModel(model_energy=energy_model, coordinate_input=1, esp_input=3, energy_output=0,
                              output_to_tensor=False, output_squeeze_states=True)(inputs)
     assert np.max(np.abs(plain["force"].values.cpu().numpy() + de_dx)) <= 2e-4 * np.max(np.abs(de_dx))
+
+
+FORK_SCHNET = dict(
+    inputs=[{"shape": [None], "name": "node_number", "dtype": "int64", "ragged": True},
+            {"shape": [None, 3], "name": "node_coordinates", "dtype": "float32", "ragged": True},
+            {"shape": [None, 2], "name": "range_indices", "dtype": "int64", "ragged": True}],
+    input_embedding={"node": {"input_dim": 95, "output_dim": 128}},
+    interaction_args={"units": 128, "use_bias": True, "activation": "shifted_softplus", "cfconv_pool": "sum"},
+    node_pooling_args={"pooling_method": "sum"}, depth=6,
+    gauss_args={"bins": 25, "distance": 5, "offset": 0.0, "sigma": 0.4}, verbose=10,
+    last_mlp={"use_bias": [True] * 3, "units": [128, 64, 1], "activation": ["shifted_softplus"] * 2 + ["linear"]},
+    output_embedding="graph", output_to_tensor=True, use_output_mlp=False, output_mlp=None)
+
+
+def _fork_schnet_case(num_graphs, seed):
+    """The fork's force_schnet.py model (force_schnet.py:33-45, 128-156): int64 node numbers, embedding 128, depth 6,
+    Gauss(25, 5.0, 0.4), last_mlp [128, 64, 1] ending linear, no output MLP."""
+    from gcnn_keras_amd.literature import Schnet
+    from helpers import dev
+    b = synth.md17_like_batch(num_graphs=num_graphs, seed=seed)
+    p = synth.schnet_params(seed=7, depth=6, emb_out=128, bins=25, last_units=(128, 64, 1), out_units=(),
+                            random_bias=True)
+    model = Schnet.make_model(**FORK_SCHNET)
+    model.set_weights(list(p.values()))
+    inputs = [dev(b["node_number"].astype(np.int64), b["node_splits"]), dev(b["node_coordinates"], b["node_splits"]),
+              dev(b["edge_indices"], b["edge_splits"])]
+    oracle = lambda xyz, pp: ko.schnet_forward(
+        pp, ko.R(b["node_number"], b["node_splits"]), ko.R(xyz, b["node_splits"]), ko.R(b["edge_indices"], b["edge_splits"]),
+        depth=6, gauss_args=FORK_SCHNET["gauss_args"], last_mlp_act=("kgcnn>shifted_softplus",) * 2 + ("linear",),
+        output_mlp_act=())
+    return b, p, model, inputs, oracle
+
+
+def test_fork_schnet_configuration_takes_the_fused_forward():
+    from parity import assert_rows_close
+    b, p, model, inputs, oracle = _fork_schnet_case(16, 5)
+    assert model.fused is not None and model.fused.accepts(inputs)
+    out = model(inputs)
+    assert model.fused.last == "direct" and torch.equal(model(inputs), out) and model.fused.last == "graph"
+    got = out.cpu().numpy()
+    assert got.shape == (16, 1)
+    assert_rows_close(got, oracle(b["node_coordinates"], p), oracle(b["node_coordinates"].astype(np.float64),
+                                                                     ko.to_dtype(p, np.float64)), what="fork SchNet")
+    layers = model(inputs, fused=False).cpu().numpy()
+    assert_rows_close(layers, oracle(b["node_coordinates"], p), what="fork SchNet, layer path")
+
+
+@pytest.mark.parametrize("fork", [True, False])
+def test_schnet_fused_energy_force(fork):
+    """Energy + forces of a SchNet energy model from one HIP graph (fused forward, hand-written reverse pass: the cfconv
+    kernel with swapped index columns for dE/dx_j, the distance-gradient MFMA kernel for dE/dd) - for the fork's
+    force_schnet.py configuration and for the reference default head - against the oracle energy, float64 finite
+    differences per molecule, the tape + layer path, and the zero-net-force property at 64 graphs."""
+    from gcnn_keras_amd import sharding
+    from gcnn_keras_amd.model.force import EnergyForceModel
+    from helpers import fd_gradient, mol_inputs
+    from parity import assert_rows_close
+    if fork:
+        b, p, energy, inputs, oracle = _fork_schnet_case(64, 2345)
+        depth, kw = 6, dict(gauss_args=FORK_SCHNET["gauss_args"],
+                            last_mlp_act=("kgcnn>shifted_softplus",) * 2 + ("linear",), output_mlp_act=())
+    else:
+        from gcnn_keras_amd.literature import Schnet
+        b = synth.qm9_like_batch(num_graphs=64, seed=2345)
+        p = synth.schnet_params(seed=7, random_bias=True)
+        energy = Schnet.make_model(depth=3)
+        energy.set_weights(list(p.values()))
+        inputs, depth, kw = mol_inputs(b), 3, {}
+        oracle = lambda xyz, pp: ko.schnet_forward(pp, ko.R(b["node_number"], b["node_splits"]), ko.R(xyz, b["node_splits"]),
+                                                   ko.R(b["edge_indices"], b["edge_splits"]), depth=3)
+    model = EnergyForceModel(model_energy=energy, coordinate_input=1, energy_output=0, output_to_tensor=False,
+                             output_squeeze_states=True, is_physical_force=not fork, output_as_dict=not fork)
+    first = model(inputs)
+    assert energy.fused.last == "eager"
+    second = model(inputs)
+    assert energy.fused.last == "graph"
+    eng, frc = (first["energy"], first["force"]) if not fork else first      # the fork asks for a tuple of outputs
+    eng2, frc2 = (second["energy"], second["force"]) if not fork else second
+    assert torch.equal(eng, eng2) and torch.equal(frc.values, frc2.values)
+    eng, force = eng.cpu().numpy(), frc.values.cpu().numpy()
+    if fork:
+        force = -force                                     # is_physical_force=False: the model returned +dE/dx
+    g_count = len(b["node_splits"]) - 1
+    assert eng.shape == (g_count, 1) and force.shape == (int(b["node_splits"][-1]), 3)
+    assert_rows_close(eng, oracle(b["node_coordinates"], p), what="SchNet energy (fused force pass)")
+    scale = float(np.max(np.abs(force)))
+    ns = b["node_splits"]
+    sums = np.stack([force[ns[g]:ns[g + 1]].sum(0) for g in range(g_count)])
+    assert np.max(np.abs(sums)) <= 2e-5 * scale
+    model.fused = False                                    # tape + layer-by-layer reverse pass
+    ref = model(inputs)
+    ref_f = (ref["force"] if not fork else ref[1]).values.cpu().numpy() * (-1.0 if fork else 1.0)
+    assert np.max(np.abs(ref_f - force)) <= 5e-5 * scale
+    p64 = ko.to_dtype(p, np.float64)
+    for g in (1, 40):
+        sub = sharding.take_shard(b, g, g + 1)
+        fn = lambda x: ko.schnet_forward(p64, ko.R(sub["node_number"], sub["node_splits"]), ko.R(x, sub["node_splits"]),
+                                         ko.R(sub["edge_indices"], sub["edge_splits"]), depth=depth, **kw)
+        fd = -fd_gradient(fn, sub["node_coordinates"])
+        got = force[ns[g]:ns[g + 1]]
+        assert np.max(np.abs(got - fd)) <= 2e-4 * max(float(np.max(np.abs(fd))), 1e-3 * scale), (fork, g)
