@@ -113,6 +113,13 @@ _SIGNATURES = {
     "mp_cos_cutoff_grad_f32": [P, c_int64, c_float, P, P, P],
     "mp_layer_norm_f32": [P, c_int64, c_int64, P, P, c_float, P, P],
     "mp_schnet_forward_launch": [P, P],
+    "mp_schnet_node_update_save_f32": [P, c_int64, P, P, P, P, P, P, P, P, c_int, P],
+    "mp_schnet_node_last_save_f32": [P, c_int64, P, P, P, P, P, P, P, P, P, P, P, P, P, c_int, P],
+    "mp_schnet_readout_grad_f32": [P, P, c_int64, P, P, P, P, P, P, P],
+    "mp_schnet_bwd_head_f32": [P, P, P, c_int64, P, P, P, P, P, P, P, P, P],
+    "mp_schnet_bwd_block_f32": [P, c_int64, P, P, P, P, P, P, P],
+    "mp_schnet_force_from_gd_f32": [P, P, P, P, P, P, P, P, P, c_int64, c_int64, c_float, P, P],
+    "mp_schnet_force_launch": [P, P],
     "mp_pack_rows_host": [P, P, c_int64, c_int64, c_int, c_int, P, P, c_int],
     "mp_pack_edge_index_host": [P, c_int, P, P, c_int64, c_int, P, P, P, P, P, P, c_int],
     "mp_host_alloc": [c_size_t, c_int, P],
@@ -135,6 +142,17 @@ class SchnetForwardDesc(ctypes.Structure):
                 + [(name, c_void_p * MP_SCHNET_MAX_DEPTH) for name in ("Wx", "packed", "W2", "b2", "W3", "b3")]
                 + [(name, c_void_p) for name in ("Wl0", "bl0", "Wl1", "bl1", "Wo0", "bo0", "Wo1", "bo1", "recv", "send",
                                                  "dist", "flags_word", "n", "x", "agg", "h", "out")])
+
+
+class SchnetForceDesc(ctypes.Structure):
+    """``mp_schnet_force_desc`` of include/mpengine.h (field for field)."""
+    _fields_ = ([("fwd", SchnetForwardDesc)]
+                + [(name, c_void_p) for name in ("xs", "d2", "dl0", "dl1", "g_pool", "node_graph")]
+                + [(name, c_void_p * MP_SCHNET_MAX_DEPTH) for name in ("W3T", "W2T", "WxT", "packed_bwd")]
+                + [(name, c_void_p) for name in ("Wl0T", "Wl1T", "seg0", "perm0", "seg1", "perm1", "ptr0", "ptr1",
+                                                 "g_n", "g_agg", "g_x", "g_d", "force")]
+                + [("force_scale", c_float)])
+
 
 _lib = None
 

@@ -15,6 +15,7 @@
 // needs no memset.
 #include "mp_common.h"
 #include "mp_edge_prepare.h"
+#include "mp_node_tile.h"
 
 // Diagnostic build (make diag -> libmpengine_diag.so, scripts/probe_node_diag.py): cycle stamps around the phases of the
 // node-update tile loop.  Compiles to nothing in the product library.
@@ -34,75 +35,6 @@ __device__ unsigned long long g_node_diag[8];
 #endif
 
 namespace {
-
-using floatx4 = __attribute__((ext_vector_type(4))) float;
-
-constexpr int F = 128;
-constexpr int X_LD = 130;  // padded row stride of the LDS activation tiles: (2*node + k) mod 32 is conflict-free
-
-__device__ __forceinline__ float ssp_exact(float x) { return mp_softplus(x) - 0.6931471805599453f; }
-// v_exp_f32 / v_log_f32 form of the shifted softplus in six VALU instructions (same as csrc/mp_cfconv.hip;
-// |delta| < 2e-7 vs ssp_exact): max(x,0) + ln2 * log2((1 + 2^(-|x| log2 e)) / 2), the max as an integer max on the bits.
-__device__ __forceinline__ float ssp_fast(float x) {
-  const float t = __builtin_amdgcn_exp2f(fabsf(x) * -1.4426950408889634f);
-  const float l = __builtin_amdgcn_logf(__builtin_fmaf(t, 0.5f, 0.5f));
-  const int xi = __float_as_int(x);
-  return __builtin_fmaf(l, 0.6931471805599453f, __int_as_float(xi > 0 ? xi : 0));
-}
-template <bool FAST>
-__device__ __forceinline__ float ssp(float x) { return FAST ? ssp_fast(x) : ssp_exact(x); }
-
-// Slice of W (K x U, row-major) for output columns col0 + 16*cb + (lane&15), k = 4*s + (lane>>4).
-template <int K, int NCB>
-__device__ __forceinline__ void load_wslice(const float* __restrict__ W, int U, int col0, int lane,
-                                            float (&wr)[NCB][K / 4]) {
-  const int g = lane >> 4, cc = lane & 15;
-#pragma unroll
-  for (int cb = 0; cb < NCB; ++cb)
-#pragma unroll
-    for (int s = 0; s < K / 4; ++s) wr[cb][s] = W[(4 * s + g) * U + col0 + 16 * cb + cc];
-}
-
-// The same slice from a pre-packed image (mp_schnet_node_pack_f32): the lane's registers of four consecutive k-steps are
-// one float4, a wave instruction reads 1 KB contiguous - 16-B loads instead of 4-B loads at a 64-B stride (the weight
-// load is ~a quarter of a node kernel's time at QM9 batch sizes, where every workgroup serves a single tile).
-template <int K, int NCB>
-__device__ __forceinline__ void load_wslice_packed(const float* __restrict__ P, int wave, int lane,
-                                                   float (&wr)[NCB][K / 4]) {
-  const float4* p4 = reinterpret_cast<const float4*>(P);
-#pragma unroll
-  for (int cb = 0; cb < NCB; ++cb)
-#pragma unroll
-    for (int q = 0; q < K / 16; ++q) {
-      const float4 v = p4[((wave * NCB + cb) * (K / 16) + q) * 64 + lane];
-      wr[cb][4 * q + 0] = v.x; wr[cb][4 * q + 1] = v.y; wr[cb][4 * q + 2] = v.z; wr[cb][4 * q + 3] = v.w;
-    }
-}
-template <int K, int NCB, bool PACKED>
-__device__ __forceinline__ void load_w(const float* __restrict__ W, int U, int wave, int lane,
-                                       float (&wr)[NCB][K / 4]) {
-  if constexpr (PACKED) load_wslice_packed<K, NCB>(W, wave, lane, wr);
-  else load_wslice<K, NCB>(W, U, wave * (U / 4), lane, wr);
-}
-
-// acc[rb][cb] += Xs(16*RB x K) @ Wslice ; A operand from LDS: lane supplies Xs[node = 16 rb + (lane&15)][k = 4s + (lane>>4)];
-// every weight register feeds RB MFMAs.
-template <int K, int NCB, int RB>
-__device__ __forceinline__ void gemm_tile(const float* __restrict__ Xs, int lane, const float (&wr)[NCB][K / 4],
-                                          floatx4 (&acc)[RB][NCB]) {
-  const float* xp = Xs + (lane & 15) * X_LD + (lane >> 4);
-#pragma unroll
-  for (int s = 0; s < K / 4; ++s) {
-    float av[RB];
-#pragma unroll
-    for (int rb = 0; rb < RB; ++rb) av[rb] = xp[rb * 16 * X_LD + 4 * s];
-#pragma unroll
-    for (int rb = 0; rb < RB; ++rb)
-#pragma unroll
-      for (int cb = 0; cb < NCB; ++cb)
-        acc[rb][cb] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[rb], wr[cb][s], acc[rb][cb], 0, 0, 0);
-  }
-}
 
 struct NodeArgs {
   int64_t N;
@@ -132,6 +64,10 @@ struct NodeArgs {
   const float* Wl1;      // (F, 64) last_mlp[1] (ssp)
   const float* bl1;
   float* h;              // (N, 64)
+  // SAVE builds (energy + force pass): d act / d pre-activation of every ssp on the chain, kept for the reverse pass
+  float* save_d2;        // (N, F)  sigmoid(agg W2 + b2)          [MID, LAST]
+  float* save_dl0;       // (N, F)  sigmoid(n Wl0 + bl0)          [LAST]
+  float* save_dl1;       // (N, 64) sigmoid(u Wl1 + bl1)          [LAST]
 };
 
 // UPD = MID without the next block's Dense_nobias, out of place: SchNetInteraction.call's node side on its own
@@ -151,7 +87,7 @@ enum NodeMode { NODE_IN = 0, NODE_MID = 1, NODE_LAST = 2, NODE_UPD = 3 };
 
 // `block` / `nblocks`: this workgroup's position among the workgroups running the node chain (the stage-0 kernel runs
 // edge preparation on the remaining workgroups of the same launch).
-template <int MODE, int E, int RB, bool FAST, bool PACKED>
+template <int MODE, int E, int RB, bool FAST, bool PACKED, bool SAVE = false>
 __device__ __forceinline__ void schnet_node_body(const NodeArgs& a, int block, int nblocks) {
   __shared__ float Xa[16 * RB * X_LD];
   __shared__ float Xb[16 * RB * X_LD];
@@ -290,7 +226,13 @@ __device__ __forceinline__ void schnet_node_body(const NodeArgs& a, int block, i
     MP_NSTAMP(1)
     MP_FOR_OUT(cb, r, row, col, {
       float v = acc[rb][cb][r] + bias_first[cb];
-      if constexpr (MODE != NODE_IN) v = ssp<FAST>(v);
+      if constexpr (MODE != NODE_IN && SAVE) {
+        float dv;
+        v = ssp_with_grad<FAST>(v, dv);
+        if (node0 + row < a.N) a.save_d2[(node0 + row) * F + col] = dv;
+      } else if constexpr (MODE != NODE_IN) {
+        v = ssp<FAST>(v);
+      }
       Xb[row * X_LD + col] = v;
       if constexpr (MODE == NODE_IN) {
         if (node0 + row < a.N) a.n[(node0 + row) * F + col] = v;
@@ -336,7 +278,17 @@ __device__ __forceinline__ void schnet_node_body(const NodeArgs& a, int block, i
           if (node0 + row < a.N) a.x[(node0 + row) * F + col] = acc[rb][cb][r];
         })
       } else {
-        MP_FOR_OUT(cb, r, row, col, { Xb[row * X_LD + col] = ssp<FAST>(acc[rb][cb][r] + bias_third[cb]); })
+        MP_FOR_OUT(cb, r, row, col, {
+          float v = acc[rb][cb][r] + bias_third[cb];
+          if constexpr (SAVE) {
+            float dv;
+            v = ssp_with_grad<FAST>(v, dv);
+            if (node0 + row < a.N) a.save_dl0[(node0 + row) * F + col] = dv;
+          } else {
+            v = ssp<FAST>(v);
+          }
+          Xb[row * X_LD + col] = v;
+        })
         __syncthreads();
         // ---- GEMM 4 (LAST): h = ssp(u @ Wl1 + bl1), 64 output columns = 16 per wave ------------------------------
         floatx4 acc4[RB][1];
@@ -349,7 +301,17 @@ __device__ __forceinline__ void schnet_node_body(const NodeArgs& a, int block, i
           for (int r = 0; r < 4; ++r) {
             const int row = 16 * rb + 4 * (lane >> 4) + r;
             const int col = wave * 16 + (lane & 15);
-            if (node0 + row < a.N) a.h[(node0 + row) * 64 + col] = ssp<FAST>(acc4[rb][0][r] + bias_fourth);
+            if (node0 + row < a.N) {
+              float v = acc4[rb][0][r] + bias_fourth;
+              if constexpr (SAVE) {
+                float dv;
+                v = ssp_with_grad<FAST>(v, dv);
+                a.save_dl1[(node0 + row) * 64 + col] = dv;
+              } else {
+                v = ssp<FAST>(v);
+              }
+              a.h[(node0 + row) * 64 + col] = v;
+            }
           }
       }
       }
@@ -364,9 +326,9 @@ __device__ __forceinline__ void schnet_node_body(const NodeArgs& a, int block, i
 #endif
 }
 
-template <int MODE, int E, int RB, bool FAST, bool PACKED>
+template <int MODE, int E, int RB, bool FAST, bool PACKED, bool SAVE>
 __global__ __launch_bounds__(256, MODE != NODE_LAST ? 2 : 1) void schnet_node_kernel(NodeArgs a) {
-  schnet_node_body<MODE, E, RB, FAST, PACKED>(a, blockIdx.x, gridDim.x);
+  schnet_node_body<MODE, E, RB, FAST, PACKED, SAVE>(a, blockIdx.x, gridDim.x);
 }
 
 // Stage 0 of the fused forward: the node-input chain (Embedding -> Dense -> Dense_nobias) and the edge preparation
@@ -391,14 +353,21 @@ __global__ __launch_bounds__(256) void schnet_readout_kernel(const float* __rest
                                                              const float* __restrict__ Wo0,
                                                              const float* __restrict__ bo0,
                                                              const float* __restrict__ Wo1,
-                                                             const float* __restrict__ bo1, float* __restrict__ out) {
+                                                             const float* __restrict__ bo1, float* __restrict__ out,
+                                                             float* __restrict__ g_pool) {
   __shared__ float Ws[64 * 64];
+  // g_pool (nullable, MLP head only): dE_g / d pooled_g (G, 64) = Wo0 (Wo1 * sigmoid(pre)) for the reverse pass; its
+  // matrix-vector product reads Wo0 by rows, from a second LDS image padded to 65 floats per row (conflict-free)
+  __shared__ float Wr[64 * 65];
   // Wo0 == NULL: linear head - the model ends in last_mlp [.., 64, 1(linear)] + PoolingNodes(sum) without an output MLP
   // (use_output_mlp=False, the fork's force configuration): out[g] = sum_n (h_n . Wo1 + bo1)
   const bool linear_head = Wo0 == nullptr;
-  if (!linear_head)
+  if (!linear_head) {
     for (int i = threadIdx.x; i < 64 * 64 / 4; i += 256)
       reinterpret_cast<float4*>(Ws)[i] = reinterpret_cast<const float4*>(Wo0)[i];
+    if (g_pool)
+      for (int i = threadIdx.x; i < 64 * 64; i += 256) Wr[(i >> 6) * 65 + (i & 63)] = Wo0[i];
+  }
   const int lane = threadIdx.x & 63;
   const float b0v = (!linear_head && bo0) ? bo0[lane] : 0.0f;
   const float w1v = Wo1[lane];
@@ -423,7 +392,18 @@ __global__ __launch_bounds__(256) void schnet_readout_kernel(const float* __rest
       y = 0.0f;
 #pragma unroll
       for (int k = 0; k < 64; ++k) y = fmaf(__int_as_float(__builtin_amdgcn_readlane(__float_as_int(pooled), k)), Ws[k * 64 + lane], y);
-      y = ssp_exact(y + b0v);
+      if (g_pool) {
+        float dy;
+        y = ssp_with_grad<false>(y + b0v, dy);
+        const float c = dy * w1v;   // dE / d pre-activation of hidden unit `lane`
+        float gp = 0.0f;
+#pragma unroll
+        for (int k = 0; k < 64; ++k)
+          gp = fmaf(Wr[lane * 65 + k], __int_as_float(__builtin_amdgcn_readlane(__float_as_int(c), k)), gp);
+        g_pool[g * 64 + lane] = gp;
+      } else {
+        y = ssp_exact(y + b0v);
+      }
     }
     float o = y * w1v;
     for (int off = 32; off > 0; off >>= 1) o += __shfl_xor(o, off, 64);
@@ -437,11 +417,11 @@ __global__ __launch_bounds__(256) void schnet_readout_kernel(const float* __rest
 // serialisation was gone - 64-node tiles spill the weights, 32-node tiles spill ~25 registers whose reloads queue behind
 // the tile prefetch (3371 vs 3328 us per forward at 225 k nodes, 397 vs 380 us at 18 k).  The persistent grid is two
 // workgroups per CU.
-template <int MODE, int E, bool FAST, bool PACKED>
+template <int MODE, int E, bool FAST, bool PACKED, bool SAVE = false>
 int launch_node_impl(NodeArgs a, hipStream_t s, const char* what) {
   a.ntiles = static_cast<int>((a.N + 15) / 16);
   const int grid = a.ntiles < 512 ? a.ntiles : 512;
-  schnet_node_kernel<MODE, E, 1, FAST, PACKED><<<grid, 256, 0, s>>>(a);
+  schnet_node_kernel<MODE, E, 1, FAST, PACKED, SAVE><<<grid, 256, 0, s>>>(a);
   return mp::check_launch(what);
 }
 
@@ -463,6 +443,11 @@ __global__ void node_pack_kernel(const float* __restrict__ W, int K, int U, floa
 
 template <int MODE, int E>
 int launch_node(const NodeArgs& a, int flags, hipStream_t s, const char* what) {
+  if constexpr (MODE == NODE_MID || MODE == NODE_LAST) {   // the energy + force pass: packed images only
+    if (a.save_d2)
+      return (flags & 1) ? launch_node_impl<MODE, E, true, true, true>(a, s, what)
+                         : launch_node_impl<MODE, E, false, true, true>(a, s, what);
+  }
   if constexpr (MODE != NODE_UPD) {   // flags bit 1: the weight pointers are mp_schnet_node_pack_f32 images
     if (flags & 2)
       return (flags & 1) ? launch_node_impl<MODE, E, true, true>(a, s, what)
@@ -544,16 +529,24 @@ int mp_schnet_stage0_f32(const float* numbers, int64_t N, const float* emb, int 
   return mp::check_launch("mp_schnet_stage0_f32");
 }
 
-int mp_schnet_node_update_f32(float* agg, int64_t N, const float* W2, const float* b2, const float* W3,
-                              const float* b3, float* n_inout, const float* Wx_next, float* x_out, int flags,
-                              mpStream_t stream) {
+int mp_schnet_node_update_save_f32(float* agg, int64_t N, const float* W2, const float* b2, const float* W3,
+                                   const float* b3, float* n_inout, const float* Wx_next, float* x_out, float* d2_out,
+                                   int flags, mpStream_t stream) {
   MP_REQUIRE(N >= 0, "mp_schnet_node_update_f32: bad sizes");
   if (N == 0) return MP_OK;
   MP_REQUIRE(agg && W2 && W3 && n_inout && Wx_next && x_out, "mp_schnet_node_update_f32: null pointer");
+  MP_REQUIRE(d2_out == nullptr || (flags & 2), "mp_schnet_node_update_save_f32: saving needs packed weight images");
   NodeArgs a{};
   a.N = N;
   a.agg = agg; a.W2 = W2; a.b2 = b2; a.W3 = W3; a.b3 = b3; a.n = n_inout; a.Wx = Wx_next; a.x = x_out;
+  a.save_d2 = d2_out;
   return launch_node<NODE_MID, 64>(a, flags, mp::as_stream(stream), "mp_schnet_node_update_f32");
+}
+
+int mp_schnet_node_update_f32(float* agg, int64_t N, const float* W2, const float* b2, const float* W3,
+                              const float* b3, float* n_inout, const float* Wx_next, float* x_out, int flags,
+                              mpStream_t stream) {
+  return mp_schnet_node_update_save_f32(agg, N, W2, b2, W3, b3, n_inout, Wx_next, x_out, nullptr, flags, stream);
 }
 
 int mp_schnet_node_pack_f32(const float* W, int K, int U, float* packed, mpStream_t stream) {
@@ -576,28 +569,47 @@ int mp_schnet_node_residual_f32(const float* agg, int64_t N, const float* W2, co
   return launch_node<NODE_UPD, 64>(a, flags, mp::as_stream(stream), "mp_schnet_node_residual_f32");
 }
 
-int mp_schnet_node_last_f32(float* agg, int64_t N, const float* W2, const float* b2, const float* W3, const float* b3,
-                            const float* n_in, const float* Wl0, const float* bl0, const float* Wl1, const float* bl1,
-                            float* h_out, int flags, mpStream_t stream) {
+int mp_schnet_node_last_save_f32(float* agg, int64_t N, const float* W2, const float* b2, const float* W3,
+                                 const float* b3, const float* n_in, const float* Wl0, const float* bl0,
+                                 const float* Wl1, const float* bl1, float* h_out, float* d2_out, float* dl0_out,
+                                 float* dl1_out, int flags, mpStream_t stream) {
   MP_REQUIRE(N >= 0, "mp_schnet_node_last_f32: bad sizes");
   if (N == 0) return MP_OK;
   MP_REQUIRE(agg && W2 && W3 && n_in && Wl0 && Wl1 && h_out, "mp_schnet_node_last_f32: null pointer");
+  MP_REQUIRE((d2_out == nullptr) == (dl0_out == nullptr) && (d2_out == nullptr) == (dl1_out == nullptr),
+             "mp_schnet_node_last_save_f32: give all three derivative buffers or none");
+  MP_REQUIRE(d2_out == nullptr || (flags & 2), "mp_schnet_node_last_save_f32: saving needs packed weight images");
   NodeArgs a{};
   a.N = N;
   a.agg = agg; a.W2 = W2; a.b2 = b2; a.W3 = W3; a.b3 = b3; a.n = const_cast<float*>(n_in);
   a.Wl0 = Wl0; a.bl0 = bl0; a.Wl1 = Wl1; a.bl1 = bl1; a.h = h_out;
+  a.save_d2 = d2_out; a.save_dl0 = dl0_out; a.save_dl1 = dl1_out;
   return launch_node<NODE_LAST, 64>(a, flags, mp::as_stream(stream), "mp_schnet_node_last_f32");
+}
+
+int mp_schnet_node_last_f32(float* agg, int64_t N, const float* W2, const float* b2, const float* W3, const float* b3,
+                            const float* n_in, const float* Wl0, const float* bl0, const float* Wl1, const float* bl1,
+                            float* h_out, int flags, mpStream_t stream) {
+  return mp_schnet_node_last_save_f32(agg, N, W2, b2, W3, b3, n_in, Wl0, bl0, Wl1, bl1, h_out, nullptr, nullptr, nullptr,
+                                      flags, stream);
+}
+
+int mp_schnet_readout_grad_f32(const float* h, const int64_t* node_splits, int64_t G, const float* Wo0,
+                               const float* bo0, const float* Wo1, const float* bo1, float* out, float* g_pool_out,
+                               mpStream_t stream) {
+  MP_REQUIRE(G >= 0, "mp_schnet_readout_f32: bad sizes");
+  if (G == 0) return MP_OK;
+  MP_REQUIRE(h && node_splits && Wo1 && out, "mp_schnet_readout_f32: null pointer");
+  MP_REQUIRE(g_pool_out == nullptr || Wo0 != nullptr, "mp_schnet_readout_grad_f32: g_pool is for the MLP head "
+             "(the linear head's dE/dh is Wo1 itself)");
+  schnet_readout_kernel<<<static_cast<unsigned>(mp::ceil_div(G, 4) < 1024 ? mp::ceil_div(G, 4) : 1024), 256, 0,
+                          mp::as_stream(stream)>>>(h, node_splits, G, Wo0, bo0, Wo1, bo1, out, g_pool_out);
+  return mp::check_launch("mp_schnet_readout_f32");
 }
 
 int mp_schnet_readout_f32(const float* h, const int64_t* node_splits, int64_t G, const float* Wo0, const float* bo0,
                           const float* Wo1, const float* bo1, float* out, mpStream_t stream) {
-  MP_REQUIRE(G >= 0, "mp_schnet_readout_f32: bad sizes");
-  if (G == 0) return MP_OK;
-  MP_REQUIRE(h && node_splits && Wo1 && out, "mp_schnet_readout_f32: null pointer");
-  schnet_readout_kernel<<<static_cast<unsigned>(mp::ceil_div(G, 4) < 1024 ? mp::ceil_div(G, 4) : 1024), 256, 0,
-                          mp::as_stream(stream)>>>(h, node_splits, G, Wo0, bo0, Wo1,
-                                                                                  bo1, out);
-  return mp::check_launch("mp_schnet_readout_f32");
+  return mp_schnet_readout_grad_f32(h, node_splits, G, Wo0, bo0, Wo1, bo1, out, nullptr, stream);
 }
 
 }  // extern "C"

@@ -504,7 +504,7 @@ class SchnetFusedRoute:
         slot = self._gslots.get(key)
         if slot is None:
             slot = FusedSchnetForce(self._p, self._packed, self._grad_images, self.depth, self.gauss,
-                                    fast_softplus=self.fast_softplus)
+                                    fast_softplus=self.fast_softplus, cfconv_flags=self.cfconv_flags)
             slot.bind(node, xyz, idx)
             while len(self._gslots) >= self.max_slots:
                 self._gslots.pop(next(iter(self._gslots)))

@@ -1,41 +1,48 @@
 """SchNet energy + forces from one HIP graph: fused forward kernels + a hand-written reverse pass
 (kgcnn/model/force.py:159-201 around kgcnn/literature/Schnet.py:104-148; the configuration of the fork's force_schnet.py).
 
-Forward: stage 0 (embedding chain + index pass + distances) and the fused cfconv kernel as in ``fused.FusedSchnet``; the
-node side runs as GEMMs that keep their pre-activations (``mp_dense_ex_f32`` with ``out_pre``) because the reverse pass
-needs ``ssp'`` of them.  Reverse, per block, last to first:
+One C-ABI call, ``mp_schnet_force_launch`` (csrc/mp_schnet_bwd.hip), issues the whole pass from a descriptor of the bound
+batch slot:
 
-    g_pre2 = (g_n W3^T) * ssp'(pre2)          g_agg = g_pre2 W2^T                           (two GEMMs, epilogue derivative)
-    g_d   += cfconv distance gradient(x_i, g_agg)          mp_cfconv_gauss_dist_grad_f32    (three MFMA chains per tile)
-    g_x    = cfconv(g_agg) with the index columns swapped  mp_cfconv_gauss_fused_f32        (the forward kernel itself)
-    g_n   += g_x Wx^T                                                                        (GEMM, addend epilogue)
+    forward   stage 0, per block cfconv + node chain - the kernels of ``fused.FusedSchnet`` in their SAVE builds, which keep
+              sigmoid(pre-activation) of every shifted softplus and the sender features x_i of every block - and the
+              readout (which also writes dE/d pooled for the MLP head)
+    reverse   head chain (5 GEMMs, one launch), then per block, last to first:
+                  g_d  += cfconv distance gradient(x_i, g_agg)      mp_cfconv_gauss_dist_grad_f32
+                  g_x   = cfconv(g_agg) with the index columns swapped (the forward kernel itself)
+                  block chain: g_n += g_x Wx^T ; g_agg = ((g_n W3^T) * d2) W2^T     (3 GEMMs, one launch)
+              and -dE/dx from g_d over both CSRs (``mp_schnet_force_from_gd_f32``).
 
-then ``-dE/dx`` from ``g_d`` over both CSRs (``mp_edge_geometry_bwd_f32``).  Block 0's input does not depend on the
-coordinates, so its ``g_x`` / ``g_n`` steps are skipped.  No tape: every saved tensor is a buffer of the batch slot.
+Block 0's input does not depend on the coordinates, so its ``g_x`` step is skipped.  No tape: every saved tensor is a
+buffer of the batch slot.  32 launches for depth 6 (the first version - one GEMM per launch - had 75 and took twice as long).
 """
 import ctypes
 
-import numpy as np
 import torch
 
 from . import _ffi
 
-_SSP = 2   # MP_ACT_SHIFTED_SOFTPLUS
+
+def _transposed_names(depth, linear_head):
+    names = ["last_mlp/0/kernel", "last_mlp/1/kernel"]
+    for i in range(depth):
+        names += ["interaction%d/dense%d/kernel" % (i, k) for k in ((2, 3) if i == 0 else (1, 2, 3))]
+    return names
 
 
 def make_grad_images(p, depth, bins, linear_head, out=None):
-    """Transposed kernels for the reverse GEMMs and the cfconv reverse images, once per weight update."""
+    """Images for the reverse pass, once per weight update: ``mp_schnet_node_pack_f32`` images of the TRANSPOSED node-side
+    kernels (``"T"``) and the cfconv reverse images (``"cf"``, ``mp_cfconv_bwd_pack_f32``).  ``out`` re-fills in place."""
     nfl = _ffi.lib().mp_cfconv_bwd_packed_floats()
-    names = ["last_mlp/0/kernel", "last_mlp/1/kernel"]
-    names += ["last_mlp/2/kernel"] if linear_head else ["output_mlp/0/kernel", "output_mlp/1/kernel"]
-    for i in range(depth):
-        names += ["interaction%d/dense%d/kernel" % (i, k) for k in (1, 2, 3)]
+    names = _transposed_names(depth, linear_head)
     if out is None:
-        out = {"T": {k: p[k].t().contiguous().clone() for k in names},
+        out = {"T": {k: torch.empty(p[k].numel(), dtype=torch.float32, device="cuda") for k in names},
                "cf": [torch.empty(nfl, dtype=torch.float32, device="cuda") for _ in range(depth)]}
-    else:
-        for k in names:
-            out["T"][k].copy_(p[k].t())
+    for k in names:
+        wt = p[k].t().contiguous()
+        _ffi.call("mp_schnet_node_pack_f32", _ffi.ptr(wt), int(wt.shape[0]), int(wt.shape[1]), _ffi.ptr(out["T"][k]),
+                  _ffi.stream())
+        torch.cuda.current_stream().synchronize()   # wt is a temporary
     for i in range(depth):
         pre = "interaction%d/cfconv/" % i
         _ffi.call("mp_cfconv_bwd_pack_f32", _ffi.ptr(p[pre + "dense1/kernel"]), _ffi.ptr(p.get(pre + "dense1/bias")),
@@ -47,10 +54,12 @@ def make_grad_images(p, depth, bins, linear_head, out=None):
 class FusedSchnetForce:
     """One batch slot of the energy + force pass."""
 
-    def __init__(self, p, images, grad_images, depth, gauss_args, fast_softplus=True):
+    def __init__(self, p, images, grad_images, depth, gauss_args, fast_softplus=True, cfconv_flags=0):
         self.p, self.w, self.gw = p, images, grad_images
         self.depth, self.gauss = int(depth), dict(gauss_args)
-        self.flags_arg = (1 if fast_softplus else 0) | 2
+        if self.depth > _ffi.MP_SCHNET_MAX_DEPTH:
+            raise ValueError("fused SchNet force pass: depth <= %d" % _ffi.MP_SCHNET_MAX_DEPTH)
+        self.flags_arg = (1 if fast_softplus else 0) | 2 | int(cfconv_flags)
         self.emb_dim = int(p["embedding"].shape[1])
         self.linear_head = "output_mlp/0/kernel" not in p
         self.stream = torch.cuda.Stream()
@@ -63,133 +72,84 @@ class FusedSchnetForce:
         self.N, self.M, self.G = n, m, g
         dev, f32 = node.values.device, torch.float32
         e = lambda *shape: torch.empty(shape, dtype=f32, device=dev)
+        z = lambda *shape: torch.zeros(shape, dtype=f32, device=dev)
         plan = idx.index_plan(node)
         if plan.flags_host() & _ffi.MP_FLAG_OOB:
             raise IndexError("edge index out of range for its graph")
-        self.ptr0, self.perm0, self.recv_sorted = plan.csr(0)
-        self.ptr1, self.perm1, self.send_sorted = plan.csr(1)
-        self.node_flags = (self.flags_arg & 3) | (256 if node.values.dtype == torch.int64 else 0)
-        mm = max(m, 1)
+        self.ptr0, self.perm0, self.seg0 = plan.csr(0)
+        self.ptr1, self.perm1, self.seg1 = plan.csr(1)
+        mm, d = max(m, 1), self.depth
         self.recv = torch.empty(mm, dtype=torch.int32, device=dev)
         self.send = torch.empty(mm, dtype=torch.int32, device=dev)
         self.flags = torch.zeros(1, dtype=torch.int32, device=dev)
-        self.dist, self.rij = e(mm), e(mm, 3)
-        d = self.depth
-        self.zero_pool = torch.zeros((2 * d, n, 128), dtype=f32, device=dev)   # agg_i and g_x_i: zero on entry
-        self.n = [e(n, 128) for _ in range(2)]
-        self.xs = [e(n, 128) for _ in range(d)]
-        self.pre2 = [e(n, 128) for _ in range(d)]
-        self.t = e(n, 128)
-        self.pl0, self.u0, self.pl1, self.h = e(n, 128), e(n, 128), e(n, 64), e(n, 64)
-        self.energy = e(g, 1)
-        if self.linear_head:
-            self.y = e(n, 1)
-        else:
-            self.pooled, self.po0, self.o0 = e(g, 64), e(g, 64), e(g, 64)
+        self.dist = e(mm)
+        self.n, self.agg, self.h, self.energy = e(n, 128), z(n, 128), e(n, 64), e(g, 1)
+        self.xs, self.d2 = e(d, n, 128), e(d, n, 128)
+        self.dl0, self.dl1 = e(n, 128), e(n, 64)
+        self.g_n, self.g_agg, self.g_x, self.g_d = e(n, 128), e(n, 128), z(n, 128), z(mm)
+        self.force = e(n, 3)
+        self.g_pool = self.node_graph = None
+        if not self.linear_head:
+            self.g_pool = e(g, 64)
+            counts = node.row_splits[1:] - node.row_splits[:-1]
+            self.node_graph = torch.repeat_interleave(torch.arange(g, dtype=torch.int32, device=dev), counts,
+                                                      output_size=n).contiguous()
         splits = node.row_splits_host()
         rows = g
         while rows > 0 and splits[rows] == splits[rows - 1]:
             rows -= 1
         self.out_rows = rows
-        # reverse pass
-        self.ones = torch.ones((g, 1), dtype=f32, device=dev)
-        self.g_small = [e(g, 64), e(g, 64)]
-        self.g_h, self.g_pl1, self.g_pl0 = e(n, 64), e(n, 64), e(n, 128)
-        self.g_y = e(n, 1)
-        self.g_n, self.g_pre2, self.g_agg = e(n, 128), e(n, 128), e(n, 128)
-        self.g_d = e(mm)
-        self.g_rij0 = torch.zeros((mm, 3), dtype=f32, device=dev)   # SchNet has no direction-dependent term
-        self.force = e(n, 3)
+        self._desc = self._descriptor()
+        self._desc_ref = ctypes.byref(self._desc)
+        self._launch_fn = _ffi.lib().mp_schnet_force_launch
         self.graph = None
 
-    @staticmethod
-    def _dense(x, rows, k, w, b, u, out, act=0, out_pre=None, grad_act=0, grad_pre=None, addend=None):
-        _ffi.call("mp_dense_ex_f32", _ffi.ptr(x), rows, k, _ffi.ptr(w), _ffi.ptr(b), u, act, 0.0, 0, grad_act, 0.0,
-                  None, _ffi.ptr(addend), _ffi.ptr(out_pre), _ffi.ptr(grad_pre), _ffi.ptr(out), _ffi.stream())
-
-    def _cfconv(self, x, packed, out, swapped=False):
-        ga = self.gauss
-        if not swapped:   # receiver-sorted list (the stable-sort permutation if the batch is not sorted)
-            seg, other, perm = (self.recv if self.perm0 is None else self.recv_sorted), self.send, self.perm0
-        else:             # sender-sorted list: out[send] += x[recv] * w
-            seg, other, perm = (self.send if self.perm1 is None else self.send_sorted), self.recv, self.perm1
-        _ffi.call("mp_cfconv_gauss_fused_f32", _ffi.ptr(x), self.N, _ffi.ptr(self.dist), int(ga["bins"]),
-                  float(ga["distance"]), float(ga["sigma"]), float(ga["offset"]), _ffi.ptr(packed), _ffi.ptr(seg),
-                  _ffi.ptr(other), _ffi.ptr(perm), self.M, self.flags_arg, _ffi.ptr(out), _ffi.stream())
+    def _descriptor(self):
+        p, w, gw, ga = self.p, self.w["node"], self.gw, self.gauss
+        node, xyz, idx = self.inputs
+        f = _ffi.SchnetForceDesc()
+        d = f.fwd
+        addr = lambda t: None if t is None else t.data_ptr()
+        d.N, d.M, d.G = self.N, self.M, self.G
+        d.depth, d.vocab, d.bins = self.depth, int(p["embedding"].shape[0]), int(ga["bins"])
+        d.flags = self.flags_arg | (256 if node.values.dtype == torch.int64 else 0)
+        d.g_distance, d.g_sigma, d.g_offset = float(ga["distance"]), float(ga["sigma"]), float(ga["offset"])
+        d.emb_dim = self.emb_dim
+        d.numbers, d.xyz, d.idx = addr(node.values), addr(xyz.values), addr(idx.values)
+        d.node_splits, d.edge_splits = addr(node.row_splits), addr(idx.row_splits)
+        d.embedding, d.W0, d.b0 = addr(p["embedding"]), addr(w["dense0/kernel"]), addr(p.get("dense0/bias"))
+        T = gw["T"]
+        for i in range(self.depth):
+            pre = "interaction%d/" % i
+            d.Wx[i], d.packed[i] = addr(w[pre + "dense1/kernel"]), addr(self.w["cfconv"][i])
+            d.W2[i], d.b2[i] = addr(w[pre + "dense2/kernel"]), addr(p.get(pre + "dense2/bias"))
+            d.W3[i], d.b3[i] = addr(w[pre + "dense3/kernel"]), addr(p.get(pre + "dense3/bias"))
+            f.W3T[i], f.W2T[i] = addr(T[pre + "dense3/kernel"]), addr(T[pre + "dense2/kernel"])
+            f.WxT[i] = addr(T.get(pre + "dense1/kernel"))
+            f.packed_bwd[i] = addr(gw["cf"][i])
+        d.Wl0, d.bl0 = addr(w["last_mlp/0/kernel"]), addr(p.get("last_mlp/0/bias"))
+        d.Wl1, d.bl1 = addr(w["last_mlp/1/kernel"]), addr(p.get("last_mlp/1/bias"))
+        if self.linear_head:
+            d.Wo0, d.bo0, d.Wo1, d.bo1 = None, None, addr(p["last_mlp/2/kernel"]), addr(p.get("last_mlp/2/bias"))
+        else:
+            d.Wo0, d.bo0 = addr(p["output_mlp/0/kernel"]), addr(p.get("output_mlp/0/bias"))
+            d.Wo1, d.bo1 = addr(p["output_mlp/1/kernel"]), addr(p.get("output_mlp/1/bias"))
+        d.recv, d.send, d.dist, d.flags_word = addr(self.recv), addr(self.send), addr(self.dist), addr(self.flags)
+        d.n, d.x, d.agg, d.h, d.out = addr(self.n), None, addr(self.agg), addr(self.h), addr(self.energy)
+        f.xs, f.d2, f.dl0, f.dl1 = addr(self.xs), addr(self.d2), addr(self.dl0), addr(self.dl1)
+        f.g_pool, f.node_graph = addr(self.g_pool), addr(self.node_graph)
+        f.Wl0T, f.Wl1T = addr(T["last_mlp/0/kernel"]), addr(T["last_mlp/1/kernel"])
+        # a column that is already sorted has no permutation: the kernels then read the column stage 0 writes
+        f.seg0, f.perm0 = (None, None) if self.perm0 is None else (addr(self.seg0), addr(self.perm0))
+        f.seg1, f.perm1 = (None, None) if self.perm1 is None else (addr(self.seg1), addr(self.perm1))
+        f.ptr0, f.ptr1 = addr(self.ptr0), addr(self.ptr1)
+        f.g_n, f.g_agg, f.g_x, f.g_d, f.force = (addr(self.g_n), addr(self.g_agg), addr(self.g_x), addr(self.g_d),
+                                                  addr(self.force))
+        f.force_scale = -1.0
+        return f
 
     def _launch(self):
-        p, w, gw, n, m, g, d = self.p, self.w, self.gw, self.N, self.M, self.G, self.depth
-        node, xyz, idx = self.inputs
-        nimg, T = w["node"], gw["T"]
-        ga = self.gauss
-        # ---------------------------------------------------------------------------------------------- forward
-        self.zero_pool.zero_()
-        _ffi.call("mp_schnet_stage0_f32", _ffi.ptr(node.values), n, _ffi.ptr(p["embedding"]),
-                  int(p["embedding"].shape[0]), self.emb_dim, _ffi.ptr(nimg["dense0/kernel"]),
-                  _ffi.ptr(p.get("dense0/bias")), _ffi.ptr(nimg["interaction0/dense1/kernel"]), _ffi.ptr(self.n[0]),
-                  _ffi.ptr(self.xs[0]), _ffi.ptr(idx.values), m, _ffi.ptr(node.row_splits), _ffi.ptr(idx.row_splits), g,
-                  _ffi.ptr(xyz.values), _ffi.ptr(self.recv), _ffi.ptr(self.send), _ffi.ptr(self.dist),
-                  _ffi.ptr(self.flags), self.node_flags, _ffi.stream())
-        if m > 0:
-            _ffi.call("mp_edge_geometry_f32", _ffi.ptr(xyz.values), n, _ffi.ptr(self.recv), _ffi.ptr(self.send), m, None,
-                      _ffi.ptr(self.rij), _ffi.stream())
-        cur = 0
-        for i in range(d):
-            pre = "interaction%d/" % i
-            agg = self.zero_pool[i]
-            self._cfconv(self.xs[i], w["cfconv"][i], agg)
-            self._dense(agg, n, 128, p[pre + "dense2/kernel"], p.get(pre + "dense2/bias"), 128, self.t, act=_SSP,
-                        out_pre=self.pre2[i])
-            self._dense(self.t, n, 128, p[pre + "dense3/kernel"], p.get(pre + "dense3/bias"), 128, self.n[1 - cur],
-                        addend=self.n[cur])
-            cur = 1 - cur
-            if i + 1 < d:
-                self._dense(self.n[cur], n, 128, p["interaction%d/dense1/kernel" % (i + 1)], None, 128, self.xs[i + 1])
-        self._dense(self.n[cur], n, 128, p["last_mlp/0/kernel"], p.get("last_mlp/0/bias"), 128, self.u0, act=_SSP,
-                    out_pre=self.pl0)
-        self._dense(self.u0, n, 128, p["last_mlp/1/kernel"], p.get("last_mlp/1/bias"), 64, self.h, act=_SSP,
-                    out_pre=self.pl1)
-        if self.linear_head:
-            self._dense(self.h, n, 64, p["last_mlp/2/kernel"], p.get("last_mlp/2/bias"), 1, self.y)
-            _ffi.call("mp_pool_graph_f32", _ffi.MP_SUM, _ffi.ptr(self.y), _ffi.ptr(node.row_splits), g, 1, None,
-                      _ffi.ptr(self.energy), _ffi.stream())
-        else:
-            _ffi.call("mp_pool_graph_f32", _ffi.MP_SUM, _ffi.ptr(self.h), _ffi.ptr(node.row_splits), g, 64, None,
-                      _ffi.ptr(self.pooled), _ffi.stream())
-            self._dense(self.pooled, g, 64, p["output_mlp/0/kernel"], p.get("output_mlp/0/bias"), 64, self.o0, act=_SSP,
-                        out_pre=self.po0)
-            self._dense(self.o0, g, 64, p["output_mlp/1/kernel"], p.get("output_mlp/1/bias"), 1, self.energy)
-        # ---------------------------------------------------------------------------------------------- reverse
-        if self.linear_head:
-            _ffi.call("mp_repeat_rows_f32", _ffi.ptr(self.ones), _ffi.ptr(node.row_splits), g, 1, n, _ffi.ptr(self.g_y),
-                      _ffi.stream())
-            self._dense(self.g_y, n, 1, T["last_mlp/2/kernel"], None, 64, self.g_pl1, grad_act=_SSP, grad_pre=self.pl1)
-        else:
-            self._dense(self.ones, g, 1, T["output_mlp/1/kernel"], None, 64, self.g_small[0], grad_act=_SSP,
-                        grad_pre=self.po0)
-            self._dense(self.g_small[0], g, 64, T["output_mlp/0/kernel"], None, 64, self.g_small[1])
-            _ffi.call("mp_repeat_rows_f32", _ffi.ptr(self.g_small[1]), _ffi.ptr(node.row_splits), g, 64, n,
-                      _ffi.ptr(self.g_h), _ffi.stream())
-            _ffi.call("mp_activation_grad_f32", _SSP, 0.0, _ffi.ptr(self.pl1), _ffi.ptr(self.g_h), n * 64,
-                      _ffi.ptr(self.g_pl1), _ffi.stream())
-        self._dense(self.g_pl1, n, 64, T["last_mlp/1/kernel"], None, 128, self.g_pl0, grad_act=_SSP, grad_pre=self.pl0)
-        self._dense(self.g_pl0, n, 128, T["last_mlp/0/kernel"], None, 128, self.g_n)
-        for i in range(d - 1, -1, -1):
-            pre = "interaction%d/" % i
-            self._dense(self.g_n, n, 128, T[pre + "dense3/kernel"], None, 128, self.g_pre2, grad_act=_SSP,
-                        grad_pre=self.pre2[i])
-            self._dense(self.g_pre2, n, 128, T[pre + "dense2/kernel"], None, 128, self.g_agg)
-            _ffi.call("mp_cfconv_gauss_dist_grad_f32", _ffi.ptr(self.xs[i]), _ffi.ptr(self.g_agg), n, _ffi.ptr(self.dist),
-                      int(ga["bins"]), float(ga["distance"]), float(ga["sigma"]), float(ga["offset"]),
-                      _ffi.ptr(gw["cf"][i]), _ffi.ptr(self.recv), _ffi.ptr(self.send), m, 0 if i == d - 1 else 1,
-                      _ffi.ptr(self.g_d), _ffi.stream())
-            if i > 0:   # block 0's x comes from the embedding: no path to the coordinates
-                g_x = self.zero_pool[d + i]
-                self._cfconv(self.g_agg, w["cfconv"][i], g_x, swapped=True)
-                self._dense(g_x, n, 128, T[pre + "dense1/kernel"], None, 128, self.g_n, addend=self.g_n)
-        _ffi.call("mp_edge_geometry_bwd_f32", _ffi.ptr(self.g_d), _ffi.ptr(self.g_rij0), 1, _ffi.ptr(self.rij),
-                  _ffi.ptr(self.dist), _ffi.ptr(self.ptr0), _ffi.ptr(self.perm0), _ffi.ptr(self.ptr1),
-                  _ffi.ptr(self.perm1), n, m, -1.0, _ffi.ptr(self.force), _ffi.stream())
+        _ffi.check(self._launch_fn(self._desc_ref, ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)))
 
     def run_current(self, how="graph"):
         """Energy ``(G', 1)`` and physical force ``(N, 3)`` of the bound batch on torch's current stream (static buffers)."""

@@ -444,6 +444,61 @@ typedef struct mp_schnet_forward_desc {
 } mp_schnet_forward_desc;
 int mp_schnet_forward_launch(const mp_schnet_forward_desc* desc_host, mpStream_t stream);
 
+/* ---------------------------------------------------------------- SchNet energy + forces ------------------- */
+/* Replaces, for a SchNet energy model, kgcnn/model/force.py:159-201 (GradientTape around the energy model, force =
+ * -dE/dx) with a forward that keeps the activation derivatives and a hand-written reverse pass.
+ *
+ * SAVE variants of the forward node chains: as mp_schnet_node_update_f32 / mp_schnet_node_last_f32 / mp_schnet_readout_f32
+ * and additionally store sigmoid(pre-activation) of every shifted softplus on the chain (d2 (N,128), dl0 (N,128),
+ * dl1 (N,64)) resp. dE_g/d pooled_g (G,64) of the MLP head.  Null outputs = the plain entry.  Packed images only. */
+int mp_schnet_node_update_save_f32(float* agg, int64_t N, const float* W2, const float* b2, const float* W3,
+                                   const float* b3, float* n_inout, const float* Wx_next, float* x_out, float* d2_out,
+                                   int flags, mpStream_t stream);
+int mp_schnet_node_last_save_f32(float* agg, int64_t N, const float* W2, const float* b2, const float* W3,
+                                 const float* b3, const float* n_in, const float* Wl0, const float* bl0,
+                                 const float* Wl1, const float* bl1, float* h_out, float* d2_out, float* dl0_out,
+                                 float* dl1_out, int flags, mpStream_t stream);
+int mp_schnet_readout_grad_f32(const float* h, const int64_t* node_splits, int64_t G, const float* Wo0,
+                               const float* bo0, const float* Wo1, const float* bo1, float* out, float* g_pool_out,
+                               mpStream_t stream);
+/* Reverse node chains on 16-node tiles; every W*T is the mp_schnet_node_pack_f32 image of the TRANSPOSED Keras kernel.
+ * head : g_n = ((gh[row] * dl1) Wl1T * dl0) Wl0T ; g_agg = ((g_n W3T) * d2) W2T     gh_row null: gh is one 64-row
+ * block: g_n += g_x WxT (g_x rows re-zeroed)     ; g_agg = ((g_n W3T) * d2) W2T */
+int mp_schnet_bwd_head_f32(const float* gh, const int32_t* gh_row, const float* dl1, int64_t N, const float* Wl1T,
+                           const float* dl0, const float* Wl0T, const float* W3T, const float* d2, const float* W2T,
+                           float* g_n, float* g_agg, mpStream_t stream);
+int mp_schnet_bwd_block_f32(float* g_x, int64_t N, const float* WxT, float* g_n, const float* W3T, const float* d2,
+                            const float* W2T, float* g_agg, mpStream_t stream);
+/* out (N,3) = scale * dE/dx from dE/dd (M): sum over the edges touching a node of g_d (x_n - x_other) / d, over the
+ * receiver-side and sender-side CSR of the index plan (perm null: that column is sorted).  scale -1: physical force. */
+int mp_schnet_force_from_gd_f32(const float* g_d, const float* xyz, const float* dist, const int32_t* recv,
+                                const int32_t* send, const int32_t* ptr0, const int32_t* perm0, const int32_t* ptr1,
+                                const int32_t* perm1, int64_t N, int64_t M, float scale, float* out, mpStream_t stream);
+/* The whole energy + force pass of a bound batch slot in one call (the ~32 launches for depth 6, in sequence on
+ * `stream`; capturable into a HIP graph): forward as mp_schnet_forward_launch with the SAVE chains (fwd.x unused: the
+ * sender features of every block are kept in xs), then head chain, per block distance gradient + swapped-column cfconv
+ * + block chain, then the force kernel.  fwd.flags bit 1 (packed node images) is required. */
+typedef struct mp_schnet_force_desc {
+  mp_schnet_forward_desc fwd;
+  float* xs;                       /* (depth, N, 128) sender features x_i of every block */
+  float* d2;                       /* (depth, N, 128) */
+  float* dl0; float* dl1;          /* (N,128), (N,64) */
+  float* g_pool;                   /* (G,64)  MLP head only */
+  const int32_t* node_graph;       /* (N) graph of each node, MLP head only */
+  const float* W3T[MP_SCHNET_MAX_DEPTH];
+  const float* W2T[MP_SCHNET_MAX_DEPTH];
+  const float* WxT[MP_SCHNET_MAX_DEPTH];           /* [0] unused */
+  const float* packed_bwd[MP_SCHNET_MAX_DEPTH];    /* mp_cfconv_bwd_pack_f32 images */
+  const float* Wl0T; const float* Wl1T;
+  const int32_t* seg0; const int32_t* perm0;       /* receiver column sorted + its permutation (null: already sorted) */
+  const int32_t* seg1; const int32_t* perm1;       /* sender column sorted + its permutation */
+  const int32_t* ptr0; const int32_t* ptr1;        /* (N+1) CSR offsets of both columns */
+  float* g_n; float* g_agg; float* g_x; float* g_d;   /* (N,128) x3 [g_x zeroed], (M) */
+  float* force;                    /* (N,3) out */
+  float force_scale;               /* -1: physical force, +1: dE/dx */
+} mp_schnet_force_desc;
+int mp_schnet_force_launch(const mp_schnet_force_desc* desc_host, mpStream_t stream);
+
 /* ---------------------------------------------------------------- host batch packer ---------------------- */
 /* The data-format side of the path.  Host pointers only; nothing here launches a kernel.
  *

@@ -290,3 +290,45 @@ def test_schnet_fused_energy_force(fork):
         fd = -fd_gradient(fn, sub["node_coordinates"])
         got = force[ns[g]:ns[g + 1]]
         assert np.max(np.abs(got - fd)) <= 2e-4 * max(float(np.max(np.abs(fd))), 1e-3 * scale), (fork, g)
+
+
+def test_schnet_fused_energy_force_unsorted_edges_weight_update_and_empty_graphs():
+    """The force route on a batch whose receivers are shuffled inside every graph (both CSR permutations in use), with a
+    trailing graph without edges... then after an in-place weight update (images of the reverse pass re-packed, same
+    captured graph), against the tape + layer path."""
+    from gcnn_keras_amd.literature import Schnet
+    from gcnn_keras_amd.model.force import EnergyForceModel
+    from helpers import dev
+    b = synth.qm9_like_batch(num_graphs=12, seed=77)
+    rng = np.random.default_rng(1)
+    idx, es = b["edge_indices"].copy(), b["edge_splits"]
+    for g in range(len(es) - 1):
+        idx[es[g]:es[g + 1]] = idx[es[g]:es[g + 1]][rng.permutation(es[g + 1] - es[g])]
+    p = synth.schnet_params(seed=3, random_bias=True)
+    energy = Schnet.make_model(depth=3)
+    energy.set_weights(list(p.values()))
+    inputs = [dev(b["node_number"], b["node_splits"]), dev(b["node_coordinates"], b["node_splits"]), dev(idx, es)]
+    model = EnergyForceModel(model_energy=energy, coordinate_input=1, energy_output=0, output_to_tensor=False,
+                             output_squeeze_states=True)
+
+    def both():
+        model.fused = None
+        model(inputs)
+        out = model(inputs)
+        assert energy.fused.last == "graph"
+        model.fused = False
+        ref = model(inputs)
+        e, f = out["energy"].cpu().numpy(), out["force"].values.cpu().numpy()
+        re, rf = ref["energy"].cpu().numpy(), ref["force"].values.cpu().numpy()
+        assert np.max(np.abs(e - re)) <= 2e-5 * np.max(np.abs(re))
+        assert np.max(np.abs(f - rf)) <= 5e-5 * np.max(np.abs(rf))
+        return f
+
+    f0 = both()
+    slots = len(energy.fused._gslots)
+    with torch.no_grad():
+        for name, t in energy.weights:
+            if name.endswith("kernel"):
+                t.mul_(1.05)
+    f1 = both()
+    assert len(energy.fused._gslots) == slots and np.max(np.abs(f1 - f0)) > 1e-3 * np.max(np.abs(f0))
