@@ -1,0 +1,277 @@
+// One or two chained Keras Dense layers on 16-row tiles with the weights in registers (kgcnn/layers/modules.py:74-87
+// applied back to back, e.g. PAiNNconv's Dense(units, act) -> Dense(3 units) of kgcnn/layers/conv/painn_conv.py:60-62,
+// PAiNNUpdate's of painn_conv.py:187-189, and their reverse forms against the transposed kernels).
+//
+// Why next to csrc/mp_dense.hip: at molecular batch sizes (N = 1-4 k rows, K and U = 128-384) the LDS-tiled GEMM there is
+// latency bound - every launch pays a cold first tile, per-k-tile barriers and an epilogue round trip: 11-17 us per GEMM
+// measured inside the PaiNN pipeline, 60 % of its energy + force pass.  Here a 512-thread workgroup owns a 16-row tile:
+// its 8 waves each hold a 1/8 column slice of BOTH weight matrices in registers (requested together with the input
+// tile: one memory round trip), the GEMMs run as v_mfma_f32_16x16x4_f32 chains from an LDS activation tile, and the
+// 128-wide intermediate never leaves the CU.  FP32 in, FP32 accumulate (k-ordered fma chains: the 1e-5 budget holds).
+//
+//   stage 1:  m = x W1 + b1 ;  [save_pre <- m] ;  m = act1(m)      or   m = (x W1) * act1'(grad_pre)   (reverse pass)
+//   stage 2:  out = m W2 + b2 + addend                              (absent: out = stage 1 + addend, any U1)
+//
+// W1 / W2 are mp_chain_pack_f32 images: the k-major register order of one wave's column slice, 16-B loads.
+#include "mp_common.h"
+
+namespace {
+
+using floatx4 = __attribute__((ext_vector_type(4))) float;
+
+constexpr int WAVES = 8;
+constexpr int MID = 128;       // width between the two stages
+constexpr int MID_LD = MID + 2;
+
+struct ChainArgs {
+  int64_t R;
+  int ntiles;
+  const float* x;          // (R, K1)
+  const float* W1;         // packed (K1, U1)
+  const float* b1;         // (U1) or null
+  int act1;
+  float alpha1;
+  float* save_pre;         // (R, U1) or null
+  const float* grad_pre;   // (R, U1) or null
+  const float* W2;         // packed (128, U2) or null
+  const float* b2;         // (U2) or null
+  const float* addend;     // (R, U_out) or null; may alias out
+  float* out;              // (R, U_out)
+};
+
+// slice of a packed image: float4 = the lane's registers of four consecutive k-steps
+template <int K, int NCB>
+__device__ __forceinline__ void load_slice(const float* __restrict__ P, int wave, int lane, float (&wr)[NCB][K / 4]) {
+  const float4* p4 = reinterpret_cast<const float4*>(P);
+#pragma unroll
+  for (int cb = 0; cb < NCB; ++cb)
+#pragma unroll
+    for (int q = 0; q < K / 16; ++q) {
+      const float4 v = p4[((wave * NCB + cb) * (K / 16) + q) * 64 + lane];
+      wr[cb][4 * q + 0] = v.x; wr[cb][4 * q + 1] = v.y; wr[cb][4 * q + 2] = v.z; wr[cb][4 * q + 3] = v.w;
+    }
+}
+
+// acc[cb] += Xs (16 x K, row stride LD) @ slice ; A operand: lane supplies Xs[lane & 15][4 s + (lane >> 4)]
+template <int K, int LD, int NCB>
+__device__ __forceinline__ void gemm16(const float* __restrict__ Xs, int lane, const float (&wr)[NCB][K / 4],
+                                       floatx4 (&acc)[NCB]) {
+  const float* xp = Xs + (lane & 15) * LD + (lane >> 4);
+#pragma unroll
+  for (int s = 0; s < K / 4; ++s) {
+    const float av = xp[4 * s];
+#pragma unroll
+    for (int cb = 0; cb < NCB; ++cb) acc[cb] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, wr[cb][s], acc[cb], 0, 0, 0);
+  }
+}
+
+// NCB2 == 0: single stage with U1 = 128 * NCB1 output columns; otherwise NCB1 == 1 (U1 = 128) and U2 = 128 * NCB2.
+template <int K1, int NCB1, int NCB2>
+__global__ __launch_bounds__(512, 1) void dense_chain_kernel(ChainArgs a) {
+  constexpr int LD1 = K1 + 2;   // bank = (2 row + k) mod 32: the 16 rows x 2 k a half-wave fetches hit 32 different banks
+  constexpr bool TWO = NCB2 > 0;
+  constexpr int U1 = 128 * NCB1;
+  constexpr int UO = TWO ? 128 * NCB2 : U1;
+  constexpr int NCBO = TWO ? NCB2 : NCB1;
+  __shared__ float Xa[16 * LD1];
+  __shared__ float Xb[TWO ? 16 * MID_LD : 1];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = tid >> 6;
+  const int nblocks = gridDim.x;
+
+  constexpr int NV = (16 * K1 / 4) / 512;   // float4 per thread and tile
+  float4 stg[NV];
+  auto stage_load = [&](int t) {
+#pragma unroll
+    for (int j = 0; j < NV; ++j) {
+      const int i = tid + j * 512;
+      const int r = i / (K1 / 4), k4 = i % (K1 / 4);
+      const int64_t row = static_cast<int64_t>(t) * 16 + r;
+      stg[j] = (t < a.ntiles && row < a.R) ? reinterpret_cast<const float4*>(a.x + row * K1)[k4]
+                                          : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+  };
+  auto stage_store = [&]() {
+#pragma unroll
+    for (int j = 0; j < NV; ++j) {
+      const int i = tid + j * 512;
+      float* d = Xa + (i / (K1 / 4)) * LD1 + 4 * (i % (K1 / 4));
+      d[0] = stg[j].x; d[1] = stg[j].y; d[2] = stg[j].z; d[3] = stg[j].w;
+    }
+  };
+  stage_load(blockIdx.x);   // first: the tile must not queue behind the weight loads
+
+  float w1[NCB1][K1 / 4];
+  float w2[TWO ? NCB2 : 1][TWO ? MID / 4 : 1];
+  load_slice<K1, NCB1>(a.W1, wave, lane, w1);
+  if constexpr (TWO) load_slice<MID, NCB2>(a.W2, wave, lane, w2);
+  float bias1[NCB1], bias2[TWO ? NCB2 : 1];
+#pragma unroll
+  for (int cb = 0; cb < NCB1; ++cb) bias1[cb] = a.b1 ? a.b1[wave * (U1 / WAVES) + 16 * cb + (lane & 15)] : 0.0f;
+  if constexpr (TWO) {
+#pragma unroll
+    for (int cb = 0; cb < NCB2; ++cb) bias2[cb] = a.b2 ? a.b2[wave * (UO / WAVES) + 16 * cb + (lane & 15)] : 0.0f;
+  }
+
+  for (int tile = blockIdx.x; tile < a.ntiles; tile += nblocks) {
+    const int64_t row0 = static_cast<int64_t>(tile) * 16;
+    stage_store();
+    __syncthreads();
+    stage_load(tile + nblocks);
+    // epilogue operands of this thread's elements, in flight during the GEMMs
+    float gp[NCB1][4], ad[NCBO][4];
+    if (a.grad_pre) {
+#pragma unroll
+      for (int cb = 0; cb < NCB1; ++cb)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int64_t row = row0 + 4 * (lane >> 4) + r;
+          gp[cb][r] = row < a.R ? a.grad_pre[row * U1 + wave * (U1 / WAVES) + 16 * cb + (lane & 15)] : 0.0f;
+        }
+    }
+    if (a.addend) {
+#pragma unroll
+      for (int cb = 0; cb < NCBO; ++cb)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int64_t row = row0 + 4 * (lane >> 4) + r;
+          ad[cb][r] = row < a.R ? a.addend[row * UO + wave * (UO / WAVES) + 16 * cb + (lane & 15)] : 0.0f;
+        }
+    }
+    floatx4 acc1[NCB1];
+#pragma unroll
+    for (int cb = 0; cb < NCB1; ++cb) acc1[cb] = floatx4{0.f, 0.f, 0.f, 0.f};
+    gemm16<K1, LD1, NCB1>(Xa, lane, w1, acc1);
+#pragma unroll
+    for (int cb = 0; cb < NCB1; ++cb)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int lrow = 4 * (lane >> 4) + r;
+        const int64_t row = row0 + lrow;
+        const int col = wave * (U1 / WAVES) + 16 * cb + (lane & 15);
+        float v = acc1[cb][r] + bias1[cb];
+        if (a.save_pre && row < a.R) a.save_pre[row * U1 + col] = v;
+        if (a.grad_pre) v *= mp_act_grad(a.act1, a.alpha1, gp[cb][r]);
+        else v = mp_apply_act(a.act1, a.alpha1, v);
+        if constexpr (TWO) {
+          Xb[lrow * MID_LD + col] = v;
+        } else {
+          if (a.addend) v += ad[cb][r];
+          if (row < a.R) a.out[row * UO + col] = v;
+        }
+      }
+    if constexpr (TWO) {
+      __syncthreads();
+      floatx4 acc2[NCB2];
+#pragma unroll
+      for (int cb = 0; cb < NCB2; ++cb) acc2[cb] = floatx4{0.f, 0.f, 0.f, 0.f};
+      gemm16<MID, MID_LD, NCB2>(Xb, lane, w2, acc2);
+#pragma unroll
+      for (int cb = 0; cb < NCB2; ++cb)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int64_t row = row0 + 4 * (lane >> 4) + r;
+          const int col = wave * (UO / WAVES) + 16 * cb + (lane & 15);
+          float v = acc2[cb][r] + bias2[cb];
+          if (a.addend) v += ad[cb][r];
+          if (row < a.R) a.out[row * UO + col] = v;
+        }
+    }
+    __syncthreads();   // Xa / Xb are reused by the next tile
+  }
+}
+
+// image element i = ((((w * ncb + cb) * (K/16) + q) * 64 + lane) * 4 + j  <-  W[4 (4q + j) + (lane >> 4)][w (U/8) + 16 cb + (lane & 15)]
+__global__ void chain_pack_kernel(const float* __restrict__ W, int K, int U, float* __restrict__ packed) {
+  const int ncb = U / (16 * WAVES), total = K * U;
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
+    const int j = i & 3, lane = (i >> 2) & 63;
+    int rest = i >> 8;
+    const int q = rest % (K / 16);
+    rest /= (K / 16);
+    const int cb = rest % ncb, w = rest / ncb;
+    const int k = 4 * (4 * q + j) + (lane >> 4);
+    const int col = w * (U / WAVES) + 16 * cb + (lane & 15);
+    packed[i] = W[k * U + col];
+  }
+}
+
+template <int K1, int NCB1, int NCB2>
+int launch_chain(ChainArgs a, hipStream_t s) {
+  a.ntiles = static_cast<int>((a.R + 15) / 16);
+  const int grid = a.ntiles < 256 ? a.ntiles : 256;   // one 512-thread workgroup per CU, persistent over the tiles
+  dense_chain_kernel<K1, NCB1, NCB2><<<grid, 512, 0, s>>>(a);
+  return mp::check_launch("mp_dense_chain_f32");
+}
+
+// register budget: the weight slices of both stages (K1/4 * NCB1 + 32 * NCB2 registers per lane) must leave room for the
+// accumulators and the prefetched tile within 256 - builds beyond 160 spill and are not instantiated
+constexpr bool chain_fits(int k1, int ncb1, int ncb2) { return k1 / 4 * ncb1 + 32 * ncb2 <= 160; }
+
+template <int K1, int NCB1, int NCB2>
+int launch_if_built(const ChainArgs& a, hipStream_t s) {
+  if constexpr (chain_fits(K1, NCB1, NCB2)) {
+    return launch_chain<K1, NCB1, NCB2>(a, s);
+  } else {
+    mp::set_error("mp_dense_chain_f32: shape not built");
+    return MP_EINVAL;
+  }
+}
+
+template <int K1>
+int dispatch_chain(const ChainArgs& a, int ncb1, int ncb2, hipStream_t s) {
+  if (ncb2 == 0) {
+    switch (ncb1) {
+      case 1: return launch_if_built<K1, 1, 0>(a, s);
+      case 2: return launch_if_built<K1, 2, 0>(a, s);
+      default: return launch_if_built<K1, 3, 0>(a, s);
+    }
+  }
+  switch (ncb2) {
+    case 1: return launch_if_built<K1, 1, 1>(a, s);
+    case 2: return launch_if_built<K1, 1, 2>(a, s);
+    default: return launch_if_built<K1, 1, 3>(a, s);
+  }
+}
+
+}  // namespace
+
+extern "C" {
+
+int mp_chain_supported(int K1, int U1, int U2) {
+  const bool k_ok = K1 == 128 || K1 == 256 || K1 == 384;
+  const auto u_ok = [](int u) { return u == 128 || u == 256 || u == 384; };
+  if (!k_ok || !u_ok(U1) || (U2 != 0 && (!u_ok(U2) || U1 != 128))) return 0;
+  return chain_fits(K1, U1 / 128, U2 / 128) ? 1 : 0;
+}
+
+int mp_chain_pack_f32(const float* W, int K, int U, float* packed, mpStream_t stream) {
+  MP_REQUIRE(W && packed, "mp_chain_pack_f32: null pointer");
+  MP_REQUIRE(K >= 16 && K % 16 == 0 && U >= 128 && U % 128 == 0, "mp_chain_pack_f32: K %% 16 == 0 and U %% 128 == 0 "
+             "required (got %d x %d)", K, U);
+  chain_pack_kernel<<<64, 256, 0, mp::as_stream(stream)>>>(W, K, U, packed);
+  return mp::check_launch("mp_chain_pack_f32");
+}
+
+int mp_dense_chain_f32(const float* x, int64_t R, int K1, const float* W1_packed, const float* b1, int U1, int act1,
+                       float alpha1, float* save_pre, const float* grad_pre, const float* W2_packed, const float* b2,
+                       int U2, const float* addend, float* out, mpStream_t stream) {
+  MP_REQUIRE(R >= 0, "mp_dense_chain_f32: bad sizes");
+  MP_REQUIRE(mp_chain_supported(K1, U1, W2_packed ? U2 : 0), "mp_dense_chain_f32: built for K1 in {128,256,384}, a "
+             "128-wide intermediate and U in {128,256,384} (got %d -> %d -> %d)", K1, U1, W2_packed ? U2 : 0);
+  MP_REQUIRE(act1 >= MP_ACT_LINEAR && act1 <= MP_ACT_LAST, "mp_dense_chain_f32: unknown activation %d", act1);
+  if (R == 0) return MP_OK;
+  MP_REQUIRE(x && W1_packed && out, "mp_dense_chain_f32: null pointer");
+  MP_REQUIRE(reinterpret_cast<uintptr_t>(x) % 16 == 0, "mp_dense_chain_f32: x must be 16-byte aligned");
+  ChainArgs a{};
+  a.R = R; a.x = x; a.W1 = W1_packed; a.b1 = b1; a.act1 = act1; a.alpha1 = alpha1; a.save_pre = save_pre;
+  a.grad_pre = grad_pre; a.W2 = W2_packed; a.b2 = b2; a.addend = addend; a.out = out;
+  const int ncb1 = U1 / 128, ncb2 = W2_packed ? U2 / 128 : 0;
+  hipStream_t s = mp::as_stream(stream);
+  if (K1 == 128) return dispatch_chain<128>(a, ncb1, ncb2, s);
+  if (K1 == 256) return dispatch_chain<256>(a, ncb1, ncb2, s);
+  return dispatch_chain<384>(a, ncb1, ncb2, s);
+}
+
+}  // extern "C"

@@ -1,9 +1,11 @@
 """Fused PaiNN forward and energy + force pass (kgcnn/literature/PAiNN.py:100-155 inside kgcnn/model/force.py:159-201).
 
-Per block five FP32-MFMA GEMMs (``mp_dense_ex_f32``: activations and their derivatives ride in the GEMM prologue,
-residual adds in its epilogue) and three memory-bound kernels (csrc/mp_painn_fused.hip): ~28 launches for a depth-3
-forward and ~26 more for the reverse pass that yields dE/dx, all replayed from ONE HIP graph per bound batch.  The reverse
-pass is written out kernel by kernel here - no tape: every saved tensor is a buffer of the batch slot.
+Per block three FP32-MFMA launches (``mp_dense_chain_f32``, csrc/mp_chain.hip: the two Dense layers of the filter net
+and of the update net each run as ONE launch with the weights in registers and the 128-wide intermediate in LDS;
+activations, their derivatives and residual adds ride in the epilogues) and three memory-bound kernels
+(csrc/mp_painn_fused.hip): ~22 launches for a depth-3 forward and ~20 more for the reverse pass that yields dE/dx, all
+replayed from ONE HIP graph per bound batch.  The reverse pass is written out kernel by kernel here - no tape: every
+saved tensor is a buffer of the batch slot.
 
     stage0    Embedding, EquivariantInitialize, index pass, r_ij, d, Bessel basis (+ d rbf / d d when forces are wanted)
     block i   h1 = z W1 + b1 | s = act(h1) Wphi + bphi | message kernel (z' = z + ds, v' = v + dv)
@@ -63,16 +65,29 @@ def make_images(p, depth, n_out, out=None):
         else:
             images[name] = value.contiguous().clone()
 
+    keep = []
+
+    def pack(name, value):
+        """``mp_chain_pack_f32`` image (register-slice order of csrc/mp_chain.hip) of a (K, U) matrix."""
+        value = value.contiguous()
+        keep.append(value)
+        if out is None:
+            images[name] = torch.empty(value.numel(), dtype=torch.float32, device=value.device)
+        _ffi.call("mp_chain_pack_f32", _ffi.ptr(value), int(value.shape[0]), int(value.shape[1]), _ffi.ptr(images[name]),
+                  _ffi.stream())
+
     images = {} if out is None else out
     for i in range(depth):
         c, u = "conv%d/" % i, "update%d/" % i
         uv = torch.cat([p[u + "lin_u/kernel"], p[u + "lin_v/kernel"]], dim=1)
-        put("uv%d" % i, uv)
-        put("uvT%d" % i, uv.t())
+        pack("uv%d/P" % i, uv)
+        pack("uvT%d/P" % i, uv.t())
         for name in (c + "dense1", c + "phi", u + "dense1", u + "a"):
-            put(name + "/T", p[name + "/kernel"].t())
+            pack(name + "/P", p[name + "/kernel"])
+            pack(name + "/TP", p[name + "/kernel"].t())
     for k in range(n_out):
         put("output_mlp/%d/T" % k, p["output_mlp/%d/kernel" % k].t())
+    torch.cuda.current_stream().synchronize()   # the packed sources in `keep` are temporaries
     return images
 
 
@@ -122,8 +137,8 @@ class FusedPainn:
         self.envd = e(mm) if (self.cos_cutoff > 0 and self.grad) else None
         self.z0, self.v0 = e(n, 128), e(n, 3, 128)
         nblk = self.depth if self.grad else 1   # the reverse pass needs every block's intermediates
-        self.blk = [{"h1": e(n, 128), "a1": e(n, 128), "s": e(n, 384), "zp": e(n, 128), "vp": e(n, 3, 128),
-                     "uv": e(3 * n, 256), "c": e(n, 256), "prod": e(n, 128), "h2": e(n, 128), "a2": e(n, 128),
+        self.blk = [{"h1": e(n, 128), "s": e(n, 384), "zp": e(n, 128), "vp": e(n, 3, 128),
+                     "uv": e(3 * n, 256), "c": e(n, 256), "prod": e(n, 128), "h2": e(n, 128),
                      "a": e(n, 384)} for _ in range(nblk)]
         nzv = self.depth if self.grad else 2    # block outputs: all of them (v_in of the next block is saved) or ping-pong
         self.zs = [e(n, 128) for _ in range(nzv)]
@@ -142,9 +157,9 @@ class FusedPainn:
             self.ones = torch.ones((g, 1), dtype=f32, device=dev)
             self.g_out = [e(g, u) for u in ([128] + self.out_units[:-1])]   # dE/d(input of output layer k)
             self.gz, self.gv = e(n, 128), e(n, 3, 128)
-            self.g_a, self.g_prod, self.g_a2, self.g_c = e(n, 384), e(n, 128), e(n, 128), e(n, 256)
+            self.g_a, self.g_prod, self.g_c = e(n, 384), e(n, 128), e(n, 256)
             self.g_zp, self.g_uv, self.g_vp = e(n, 128), e(3 * n, 256), e(n, 3, 128)
-            self.g_s, self.g_a1 = e(n, 384), e(n, 128)
+            self.g_s = e(n, 384)
             self.g_d, self.g_rij = e(2, mm), e(2, mm, 3)   # one slice per feature half of the reverse message kernel
             self.force = e(n, 3)
         self.graphs = {}
@@ -155,6 +170,14 @@ class FusedPainn:
         """out = act(x W + b) [* grad_act'(grad_pre)] [+ addend]; out_pre additionally keeps x W + b."""
         _ffi.call("mp_dense_ex_f32", _ffi.ptr(x), rows, k, _ffi.ptr(w), _ffi.ptr(b), u, act, 0.0, 0, grad_act, 0.0,
                   None, _ffi.ptr(addend), _ffi.ptr(out_pre), _ffi.ptr(grad_pre), _ffi.ptr(out), _ffi.stream())
+
+    @staticmethod
+    def _chain(x, rows, k1, w1, b1, u1, out, act=0, save_pre=None, grad_pre=None, w2=None, b2=None, u2=0, addend=None):
+        """One or two Dense layers in one launch (csrc/mp_chain.hip): m = act(x W1 + b1) [save_pre keeps x W1 + b1], or
+        m = (x W1) * act'(grad_pre) in the reverse pass; out = m W2 + b2 + addend (W2 absent: out = m + addend)."""
+        _ffi.call("mp_dense_chain_f32", _ffi.ptr(x), rows, k1, _ffi.ptr(w1), _ffi.ptr(b1), u1, act, 0.0,
+                  _ffi.ptr(save_pre), _ffi.ptr(grad_pre), _ffi.ptr(w2), _ffi.ptr(b2), u2, _ffi.ptr(addend), _ffi.ptr(out),
+                  _ffi.stream())
 
     def _forward(self):
         p, w, n, m = self.p, self.w, self.N, self.M
@@ -173,19 +196,17 @@ class FusedPainn:
             t = self.blk[i if self.grad else 0]
             z_out, v_out = self.zs[i % len(self.zs)], self.vs[i % len(self.vs)]
             # Dense(act) writes the activation and (for the reverse pass) keeps the pre-activation h1 beside it
-            self._dense(z, n, 128, p[c + "dense1/kernel"], p.get(c + "dense1/bias"), 128, t["a1"], act=self.act_conv,
-                        out_pre=t["h1"] if self.grad else None)
-            self._dense(t["a1"], n, 128, p[c + "phi/kernel"], p.get(c + "phi/bias"), 384, t["s"])
+            self._chain(z, n, 128, w[c + "dense1/P"], p.get(c + "dense1/bias"), 128, t["s"], act=self.act_conv,
+                        save_pre=t["h1"] if self.grad else None, w2=w[c + "phi/P"], b2=p.get(c + "phi/bias"), u2=384)
             _ffi.call("mp_painn_message_f32", _ffi.ptr(t["s"]), _ffi.ptr(v), n, _ffi.ptr(self.rbf), self.B,
                       _ffi.ptr(self.env), _ffi.ptr(self.rij), _ffi.ptr(p[c + "w/kernel"]), _ffi.ptr(p.get(c + "w/bias")),
                       _ffi.ptr(self.ptr0), _ffi.ptr(self.perm0), _ffi.ptr(self.send), m, _ffi.ptr(z), _ffi.ptr(t["zp"]),
                       _ffi.ptr(t["vp"]), _ffi.stream())
-            self._dense(t["vp"], 3 * n, 128, w["uv%d" % i], None, 256, t["uv"])
+            self._chain(t["vp"], 3 * n, 128, w["uv%d/P" % i], None, 256, t["uv"])
             _ffi.call("mp_painn_update_pre_f32", _ffi.ptr(t["zp"]), _ffi.ptr(t["uv"]), n, _ffi.ptr(t["c"]),
                       _ffi.ptr(t["prod"]), _ffi.stream())
-            self._dense(t["c"], n, 256, p[u + "dense1/kernel"], p.get(u + "dense1/bias"), 128, t["a2"], act=self.act_upd,
-                        out_pre=t["h2"] if self.grad else None)
-            self._dense(t["a2"], n, 128, p[u + "a/kernel"], p.get(u + "a/bias"), 384, t["a"])
+            self._chain(t["c"], n, 256, w[u + "dense1/P"], p.get(u + "dense1/bias"), 128, t["a"], act=self.act_upd,
+                        save_pre=t["h2"] if self.grad else None, w2=w[u + "a/P"], b2=p.get(u + "a/bias"), u2=384)
             _ffi.call("mp_painn_update_post_f32", _ffi.ptr(t["zp"]), _ffi.ptr(t["vp"]), _ffi.ptr(t["uv"]),
                       _ffi.ptr(t["prod"]), _ffi.ptr(t["a"]), n, _ffi.ptr(z_out), _ffi.ptr(v_out), _ffi.stream())
             z, v = z_out, v_out
@@ -221,12 +242,12 @@ class FusedPainn:
             v_in = self.v0 if i == 0 else self.vs[i - 1]
             _ffi.call("mp_painn_update_post_bwd_f32", _ffi.ptr(self.gz), _ffi.ptr(self.gv), _ffi.ptr(b["uv"]),
                       _ffi.ptr(b["prod"]), _ffi.ptr(b["a"]), n, _ffi.ptr(self.g_a), _ffi.ptr(self.g_prod), _ffi.stream())
-            self._dense(self.g_a, n, 384, w[u + "a/T"], None, 128, self.g_a2, grad_act=self.act_upd, grad_pre=b["h2"])
-            self._dense(self.g_a2, n, 128, w[u + "dense1/T"], None, 256, self.g_c)
+            self._chain(self.g_a, n, 384, w[u + "a/TP"], None, 128, self.g_c, act=self.act_upd, grad_pre=b["h2"],
+                        w2=w[u + "dense1/TP"], u2=256)
             _ffi.call("mp_painn_update_pre_bwd_f32", _ffi.ptr(self.gz), _ffi.ptr(self.gv), _ffi.ptr(b["uv"]),
                       _ffi.ptr(b["c"]), _ffi.ptr(b["a"]), _ffi.ptr(self.g_prod), _ffi.ptr(self.g_c), n,
                       _ffi.ptr(self.g_zp), _ffi.ptr(self.g_uv), _ffi.stream())
-            self._dense(self.g_uv, 3 * n, 256, w["uvT%d" % i], None, 128, self.g_vp, addend=self.gv)
+            self._chain(self.g_uv, 3 * n, 256, w["uvT%d/P" % i], None, 128, self.g_vp, addend=self.gv)
             _ffi.call("mp_painn_message_bwd_f32", _ffi.ptr(b["s"]), _ffi.ptr(v_in), n, _ffi.ptr(self.rbf),
                       _ffi.ptr(self.rbfd), self.B, _ffi.ptr(self.env), _ffi.ptr(self.envd), _ffi.ptr(self.rij),
                       _ffi.ptr(p[c + "w/kernel"]), _ffi.ptr(p.get(c + "w/bias")), _ffi.ptr(self.ptr1),
@@ -234,9 +255,8 @@ class FusedPainn:
                       _ffi.ptr(self.g_s), _ffi.ptr(self.gv) if i > 0 else None, _ffi.ptr(self.g_d), _ffi.ptr(self.g_rij),
                       0 if i == self.depth - 1 else 1, _ffi.stream())
             if i > 0:   # block 0's inputs (embedding, constant v) do not depend on the coordinates
-                self._dense(self.g_s, n, 384, w[c + "phi/T"], None, 128, self.g_a1, grad_act=self.act_conv,
-                            grad_pre=b["h1"])
-                self._dense(self.g_a1, n, 128, w[c + "dense1/T"], None, 128, self.gz, addend=self.g_zp)
+                self._chain(self.g_s, n, 384, w[c + "phi/TP"], None, 128, self.gz, act=self.act_conv, grad_pre=b["h1"],
+                            w2=w[c + "dense1/TP"], u2=128, addend=self.g_zp)
         _ffi.call("mp_edge_geometry_bwd_f32", _ffi.ptr(self.g_d), _ffi.ptr(self.g_rij), 2, _ffi.ptr(self.rij),
                   _ffi.ptr(self.dist), _ffi.ptr(self.ptr0), _ffi.ptr(self.perm0), _ffi.ptr(self.ptr1),
                   _ffi.ptr(self.perm1), n, m, -1.0, _ffi.ptr(self.force), _ffi.stream())

@@ -444,6 +444,20 @@ typedef struct mp_schnet_forward_desc {
 } mp_schnet_forward_desc;
 int mp_schnet_forward_launch(const mp_schnet_forward_desc* desc_host, mpStream_t stream);
 
+/* ---------------------------------------------------------------- Dense chains on 16-row tiles ------------ */
+/* One or two Keras Dense layers back to back (kgcnn/layers/modules.py:74-87; PAiNNconv / PAiNNUpdate's
+ * Dense(units, act) -> Dense(3 units), kgcnn/layers/conv/painn_conv.py:60-62,187-189, and their reverse forms) in one
+ * launch, weights in registers, the 128-wide intermediate in LDS - the latency-bound regime of molecular batches:
+ *   m = x W1 + b1 ; [save_pre <- m] ; m = act1(m)        or, with grad_pre:  m = (x W1 + b1) * act1'(grad_pre)
+ *   out = m W2 + b2 + addend                              W2_packed null: out = m + addend (U1 columns)
+ * K1 in {128,256,384}; two stages: U1 = 128, U2 in {128,256,384}; one stage: U1 in {128,256,384}.  W*_packed are
+ * mp_chain_pack_f32 images of the Keras kernels (K, U).  addend may alias out.  mp_chain_supported: 1 if built. */
+int mp_chain_supported(int K1, int U1, int U2);
+int mp_chain_pack_f32(const float* W, int K, int U, float* packed, mpStream_t stream);
+int mp_dense_chain_f32(const float* x, int64_t R, int K1, const float* W1_packed, const float* b1, int U1, int act1,
+                       float alpha1, float* save_pre, const float* grad_pre, const float* W2_packed, const float* b2,
+                       int U2, const float* addend, float* out, mpStream_t stream);
+
 /* ---------------------------------------------------------------- SchNet energy + forces ------------------- */
 /* Replaces, for a SchNet energy model, kgcnn/model/force.py:159-201 (GradientTape around the energy model, force =
  * -dE/dx) with a forward that keeps the activation derivatives and a hand-written reverse pass.

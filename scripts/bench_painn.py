@@ -105,7 +105,11 @@ def main():
                   _ffi.ptr(slot.g_rij), 0, _ffi.stream())
 
     def gemm():
-        slot._dense(blk["vp"], 3 * n, 128, w["uv1"], None, 256, blk["uv"])
+        slot._chain(blk["vp"], 3 * n, 128, w["uv1/P"], None, 256, blk["uv"])
+
+    def gemm2():
+        slot._chain(slot.zs[0], n, 128, w["conv1/dense1/P"], p.get("conv1/dense1/bias"), 128, blk["s"], act=slot.act_conv,
+                    save_pre=blk["h1"], w2=w["conv1/phi/P"], b2=p.get("conv1/phi/bias"), u2=384)
 
     f = 128
     kernels = {}
@@ -114,8 +118,10 @@ def main():
              "hbm"),
             ("painn_message_bwd_kernel", msg_bwd, m * (12 * 20 * f + 30 * f),
              4 * (3 * n * f * 2 + 4 * n * f + 6 * n * f) + m * (8 * 20 + 40), "hbm"),
-            ("dense_mfma_kernel (3N,128)x(128,256)", gemm, 2 * 3 * n * 128 * 256, 4 * (3 * n * 128 + 128 * 256 + 3 * n * 256),
-             "mfma")):
+            ("dense_chain_kernel (3N,128)x(128,256)", gemm, 2 * 3 * n * 128 * 256, 4 * (3 * n * 128 + 128 * 256 + 3 * n * 256),
+             "mfma"),
+            ("dense_chain_kernel (N,128)x(128,128)x(128,384)", gemm2, 2 * n * 128 * (128 + 384),
+             4 * (n * 128 * 2 + 128 * 512 + n * 384), "mfma")):
         ms = timer.time_ms(fn, 50)
         kernels[name] = {"avg_launch_us": ms * 1e3, "algorithmic_flops": flops, "algorithmic_bytes": nbytes,
                          "bound": bound, "tflops": flops / (ms * 1e-3) / 1e12, "gbs": nbytes / (ms * 1e-3) / 1e9,
