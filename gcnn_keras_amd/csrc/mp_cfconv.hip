@@ -125,7 +125,8 @@ __global__ __launch_bounds__(WAVES * 64, (WAVES == 4 && COMPACT) ? 2 : 1) void c
 
   // ---- per-tile edge data is fetched one tile ahead (the first tile's before the weight staging) so that its
   //      latency (perm -> send / dist is a dependent chain) hides under staging resp. the previous tile's MFMAs -----
-  const int tile_first = blockIdx.x * WAVES + wave;
+  // XCD-aware block order (mp_common.h): consecutive edge tiles - the same molecules' sender rows - share one XCD's L2
+  const int tile_first = static_cast<int>(mp_xcd_block(blockIdx.x, gridDim.x)) * WAVES + wave;
   const int tile_step = gridDim.x * WAVES;
   int nx_send = 0, nx_recv = 0;
   float nx_d = 0.0f;

@@ -69,7 +69,9 @@ __global__ __launch_bounds__(WAVES * 64, 1) void cfconv_dist_grad_kernel(CfconvB
   const float* w2_lane = W2s + hh * F + 4 * c;          // + 2s*F: row j = 2s + hh
   const float fbins = static_cast<float>(B);
 
-  for (int tile = blockIdx.x * WAVES + wave; tile < a.ntiles; tile += gridDim.x * WAVES) {
+  // XCD-aware block order (mp_common.h): consecutive edge tiles share one XCD's L2
+  for (int tile = static_cast<int>(mp_xcd_block(blockIdx.x, gridDim.x)) * WAVES + wave; tile < a.ntiles;
+       tile += gridDim.x * WAVES) {
     const int64_t e0 = static_cast<int64_t>(tile) * TE;
     const int64_t e_mine = e0 + c;                      // lane c (both halves) <-> edge c of the tile
     const bool valid = e_mine < a.M;

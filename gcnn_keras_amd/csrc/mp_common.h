@@ -55,6 +55,17 @@ inline unsigned grid_for(int64_t work_items, int block = 256) {
 // Activation functors shared by the dense epilogue and the standalone activation kernel.
 // shifted_softplus restates kgcnn/ops/activ.py:15 with TF's thresholded softplus
 // (x > -thr -> x ; x < thr -> exp(x) ; else log1p(exp(x)), thr = log(eps_f32) + 2).
+// XCD-aware block order.  The hardware deals workgroups to the 8 XCDs round-robin (workgroup b runs on XCD b % 8), and each
+// XCD has its own L2: a kernel whose blocks walk nodes / edges in order touches every molecule from every XCD, so all
+// eight L2s fetch the whole working set.  Mapping block b to logical block `mp_xcd_block(b, grid)` gives XCD k one
+// contiguous range of logical blocks (of size grid/8, +1 for the first grid%8 XCDs - exactly the blocks it is dealt),
+// so each L2 holds one eighth of the batch.  A bijection on [0, grid).
+__device__ __forceinline__ unsigned mp_xcd_block(unsigned b, unsigned grid) {
+  const unsigned k = b & 7u, i = b >> 3;
+  const unsigned q = grid >> 3, r = grid & 7u;
+  return k * q + (k < r ? k : r) + i;
+}
+
 // OR a thread's MP_FLAG_* bits into the batch's flag word: reduced across the wave first (three ballots), published by
 // one lane, and only if the word does not hold the bits yet - an unsorted column raises its bit in nearly every thread,
 // and 2.5 M same-address atomics cost more than the rest of the index pass (measured 80 of 111 us).

@@ -177,7 +177,8 @@ __global__ __launch_bounds__(256) void painn_message_kernel(PainnMsgArgs a) {
   const int lane = threadIdx.x & 63;
   const int B = BT > 0 ? BT : a.B;
   const int64_t nwaves = (static_cast<int64_t>(gridDim.x) * blockDim.x) >> 6;
-  const int64_t wave0 = (static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x) >> 6;
+  // XCD-aware: consecutive nodes (one molecule's rows of s / v and its edges) stay in one XCD's L2
+  const int64_t wave0 = (static_cast<int64_t>(mp_xcd_block(blockIdx.x, gridDim.x)) * blockDim.x + threadIdx.x) >> 6;
   const int half = __builtin_amdgcn_readfirstlane(static_cast<int>(wave0 & 1));   // nwaves is even: fixed per wave
   const int f0 = half * 64 + lane;                                                 // this lane's feature
   float w[3][MAXB], bias[3];
@@ -301,7 +302,8 @@ __global__ __launch_bounds__(256) void painn_message_bwd_kernel(PainnMsgBwdArgs 
   const int lane = threadIdx.x & 63;
   const int B = BT > 0 ? BT : a.B;
   const int64_t nwaves = (static_cast<int64_t>(gridDim.x) * blockDim.x) >> 6;
-  const int64_t wave0 = (static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x) >> 6;
+  // XCD-aware: consecutive nodes (one molecule's rows of s / v and its edges) stay in one XCD's L2
+  const int64_t wave0 = (static_cast<int64_t>(mp_xcd_block(blockIdx.x, gridDim.x)) * blockDim.x + threadIdx.x) >> 6;
   const int half = __builtin_amdgcn_readfirstlane(static_cast<int>(wave0 & 1));
   const int f0 = half * 64 + lane;
   float* const g_d = a.g_d + static_cast<int64_t>(half) * a.M;

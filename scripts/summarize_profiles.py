@@ -36,7 +36,8 @@ def kernel_stats(run_dir, out_name, title):
 
 def pmc(fetch_dir, write_dir, label):
     def agg(d):
-        files = glob.glob(os.path.join(ROOT, "gpurun_out", d, "*", "*counter_collection.csv"))
+        files = (glob.glob(os.path.join(ROOT, "gpurun_out", d, "*", "*counter_collection.csv"))
+                 + glob.glob(os.path.join(ROOT, "gpurun_out", d, "*counter_collection.csv")))
         acc = collections.defaultdict(list)
         if files:
             for r in csv.DictReader(open(files[0])):
@@ -56,6 +57,15 @@ def pmc(fetch_dir, write_dir, label):
 
 
 os.makedirs(os.path.join(ROOT, "profiles"), exist_ok=True)
+if tag != "r01":   # round 2 on: kernel statistics come from rocprof_db_stats.py; this script condenses the --pmc passes
+    res = [pmc("pmc2_fetch", "pmc2_write", "config 2 (128 graphs, N=2301, M=26190): bench.py --in-flight 1, forward"),
+           pmc("pmc2_sf_fetch", "pmc2_sf_write", "scripts/bench_schnet_force.py 64 --profile fork: SchNet energy+force, "
+               "fork configuration (depth 6, 25 bins), N=1344, M=20586"),
+           pmc("pmc2_pn_fetch", "pmc2_pn_write", "scripts/profile_painn.py force: PaiNN energy+force, config 3, N=1344, "
+               "M=20586")]
+    json.dump(res, open(os.path.join(ROOT, "profiles", "%s_pmc_hbm_traffic.json" % tag), "w"), indent=1)
+    print("profiles written")
+    sys.exit(0)
 kernel_stats("prof_layers", "%s_layers_mode_kernel_stats.csv" % tag, "bench.py --mode layers (one engine call per Keras layer), config 2")
 kernel_stats("prof_fused4", "%s_fused_config2_kernel_stats.csv" % tag, "bench.py --in-flight 1 (fused, HIP graph, one forward at a time), config 2: 128 graphs")
 kernel_stats("prof_inflight", "%s_fused_config2_inflight4_kernel_stats.csv" % tag, "bench.py (default: 4 batches in flight on 4 streams; kernel durations include time shared with other batches), config 2")
