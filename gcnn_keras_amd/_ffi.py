@@ -120,6 +120,7 @@ _SIGNATURES = {
     "mp_schnet_bwd_block_f32": [P, c_int64, P, P, P, P, P, P, P],
     "mp_schnet_force_from_gd_f32": [P, P, P, P, P, P, P, P, P, c_int64, c_int64, c_float, P, P],
     "mp_schnet_force_launch": [P, P],
+    "mp_pool_mlp2_f32": [P, P, c_int64, c_int, P, P, c_int, c_int, c_float, P, P, P, P, P],
     "mp_chain_supported": [c_int, c_int, c_int],
     "mp_chain_pack_f32": [P, c_int, c_int, P, P],
     "mp_dense_chain_f32": [P, c_int64, c_int, P, P, c_int, c_int, c_float, P, P, P, P, c_int, P, P, P],

@@ -109,6 +109,8 @@ class FusedPainn:
         self.v_init = float(init.get("value", 1.0)) if init.get("method") == "const" else _CONST_INIT[init.get("method", "zeros")]
         cutoff = cfg["conv_args"].get("cutoff")
         self.cos_cutoff = float(cutoff) if cutoff is not None else -1.0
+        # readout in one launch (mp_pool_mlp2_f32) for the two-layer heads [H, 1]; other heads: pool + Dense launches
+        self.fast_readout = len(self.out_units) == 2 and self.out_units[0] in (64, 128) and self.out_units[1] == 1
         self.stream = torch.cuda.Stream()
         self.graphs = {}
         self.calls = 0
@@ -179,7 +181,7 @@ class FusedPainn:
                   _ffi.ptr(save_pre), _ffi.ptr(grad_pre), _ffi.ptr(w2), _ffi.ptr(b2), u2, _ffi.ptr(addend), _ffi.ptr(out),
                   _ffi.stream())
 
-    def _forward(self):
+    def _forward(self, with_forces=False):
         p, w, n, m = self.p, self.w, self.N, self.M
         node, xyz, idx = self.inputs
         _ffi.call("mp_painn_stage0_f32", _ffi.ptr(node.values), 1 if node.values.dtype == torch.int64 else 0, n,
@@ -210,6 +212,12 @@ class FusedPainn:
             _ffi.call("mp_painn_update_post_f32", _ffi.ptr(t["zp"]), _ffi.ptr(t["vp"]), _ffi.ptr(t["uv"]),
                       _ffi.ptr(t["prod"]), _ffi.ptr(t["a"]), n, _ffi.ptr(z_out), _ffi.ptr(v_out), _ffi.stream())
             z, v = z_out, v_out
+        if self.fast_readout:   # PoolingNodes(sum) + MLP([H, 1]) - and, for forces, dE/dz of the readout - in one launch
+            _ffi.call("mp_pool_mlp2_f32", _ffi.ptr(z), _ffi.ptr(node.row_splits), self.G, 128,
+                      _ffi.ptr(p["output_mlp/0/kernel"]), _ffi.ptr(p.get("output_mlp/0/bias")), self.out_units[0],
+                      self.act_out[0], 0.0, _ffi.ptr(p["output_mlp/1/kernel"]), _ffi.ptr(p.get("output_mlp/1/bias")),
+                      _ffi.ptr(self.post_out[-1]), _ffi.ptr(self.gz) if with_forces else None, _ffi.stream())
+            return
         # PoolingNodes(sum) + output MLP (PAiNN.py:146-147); every layer keeps its pre-activation
         _ffi.call("mp_pool_graph_f32", _ffi.MP_SUM, _ffi.ptr(z), _ffi.ptr(node.row_splits), self.G, 128, None,
                   _ffi.ptr(self.pooled), _ffi.stream())
@@ -228,13 +236,15 @@ class FusedPainn:
         node = self.inputs[0]
         last = len(self.out_units) - 1
         t, k_in = self.ones, self.out_units[-1]
-        for k in range(last, -1, -1):   # t = dE/d pre_k -> dE/d pre_{k-1} = (t W_k^T) * act_{k-1}'(pre_{k-1})
+        for k in range(last, -1, -1) if not self.fast_readout else ():   # fast readout: the forward wrote gz already
+            # t = dE/d pre_k -> dE/d pre_{k-1} = (t W_k^T) * act_{k-1}'(pre_{k-1})
             width = 128 if k == 0 else self.out_units[k - 1]
             self._dense(t, self.G, k_in, w["output_mlp/%d/T" % k], None, width, self.g_out[k],
                         grad_act=self.act_out[k - 1] if k > 0 else 0, grad_pre=self.pre_out[k - 1] if k > 0 else None)
             t, k_in = self.g_out[k], width
-        _ffi.call("mp_repeat_rows_f32", _ffi.ptr(t), _ffi.ptr(node.row_splits), self.G, 128, n, _ffi.ptr(self.gz),
-                  _ffi.stream())
+        if not self.fast_readout:
+            _ffi.call("mp_repeat_rows_f32", _ffi.ptr(t), _ffi.ptr(node.row_splits), self.G, 128, n, _ffi.ptr(self.gz),
+                      _ffi.stream())
         self.gv.zero_()                 # the readout sees z only
         for i in range(self.depth - 1, -1, -1):
             c, u = "conv%d/" % i, "update%d/" % i
@@ -262,7 +272,7 @@ class FusedPainn:
                   _ffi.ptr(self.perm1), n, m, -1.0, _ffi.ptr(self.force), _ffi.stream())
 
     def _launch(self, with_forces):
-        self._forward()
+        self._forward(with_forces)
         if with_forces:
             self._backward()
 

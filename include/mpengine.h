@@ -458,6 +458,13 @@ int mp_dense_chain_f32(const float* x, int64_t R, int K1, const float* W1_packed
                        float alpha1, float* save_pre, const float* grad_pre, const float* W2_packed, const float* b2,
                        int U2, const float* addend, float* out, mpStream_t stream);
 
+/* Graph readout in one launch: PoolingNodes(sum) over x (N,K) (kgcnn/layers/pooling.py:215-218) followed by the
+ * two-layer output MLP Dense(H, act0) -> Dense(1, linear) (kgcnn/literature/PAiNN.py:146-147): out (G,1).  g_x (nullable,
+ * (N,K)): also the reverse of this readout, dE_g/dx_n = W0 (W1 * act0'(pre_g)) written to every node row of graph g
+ * (what tape.gradient yields there, kgcnn/model/force.py:159-177).  K, H in {64, 128}. */
+int mp_pool_mlp2_f32(const float* x, const int64_t* node_splits, int64_t G, int K, const float* W0, const float* b0, int H,
+                     int act0, float alpha0, const float* W1, const float* b1, float* out, float* g_x, mpStream_t stream);
+
 /* ---------------------------------------------------------------- SchNet energy + forces ------------------- */
 /* Replaces, for a SchNet energy model, kgcnn/model/force.py:159-201 (GradientTape around the energy model, force =
  * -dE/dx) with a forward that keeps the activation derivatives and a hand-written reverse pass.

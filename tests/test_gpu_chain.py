@@ -88,3 +88,26 @@ def test_unbuilt_shapes_are_refused():
     with pytest.raises(ValueError):
         _ffi.call("mp_dense_chain_f32", _ffi.ptr(x), 16, 384, _ffi.ptr(w), None, 384, 0, 0.0, None, None, None, None, 0,
                   None, _ffi.ptr(out), _ffi.stream())
+
+
+@pytest.mark.parametrize("k,h,act", [(128, 128, "swish"), (128, 64, "shifted_softplus"), (64, 64, "relu"), (64, 128, "linear")])
+def test_pool_mlp2_readout_and_its_reverse(k, h, act):
+    """mp_pool_mlp2_f32: PoolingNodes(sum) + Dense(h, act) + Dense(1) per graph, and dE_g/dx rows, vs float64 torch
+    (autograd for the reverse); ragged graphs incl. an empty one in the middle and at the end (written as bias-only rows)."""
+    rng = np.random.default_rng(k + h)
+    sizes = [5, 0, 21, 1, 9, 33, 0]
+    splits = torch.from_numpy(np.concatenate([[0], np.cumsum(sizes)]).astype(np.int64)).cuda()
+    n, g = int(sum(sizes)), len(sizes)
+    x, w0, b0, w1, b1 = _rand(rng, n, k), _rand(rng, k, h, scale=0.2), _rand(rng, h), _rand(rng, h, 1), _rand(rng, 1)
+    out, gx = torch.empty(g, 1, device="cuda"), torch.full((n, k), 7.0, device="cuda")
+    _ffi.call("mp_pool_mlp2_f32", _ffi.ptr(x), _ffi.ptr(splits), g, k, _ffi.ptr(w0), _ffi.ptr(b0), h,
+              _ffi.activation_code(act), 0.0, _ffi.ptr(w1), _ffi.ptr(b1), _ffi.ptr(out), _ffi.ptr(gx), _ffi.stream())
+    torch.cuda.synchronize()
+    f = lambda t: t.double().cpu()
+    x64 = f(x).requires_grad_(True)
+    seg = torch.repeat_interleave(torch.arange(g), torch.tensor(sizes))
+    pooled = torch.zeros(g, k, dtype=torch.float64).index_add(0, seg, x64)
+    want = _ACT64[act](pooled @ f(w0) + f(b0)) @ f(w1) + f(b1)
+    want.sum().backward()
+    _close(out, want.detach())
+    _close(gx, x64.grad)
