@@ -43,6 +43,22 @@ __device__ __forceinline__ float wave_sum(float v) {
   return v;
 }
 
+// Wave-wide sum on the VALU's DPP path, result wave-uniform: two quad permutes, row_half_mirror, row_mirror (after which
+// every lane of a 16-lane row holds the row's sum) and four v_readlane for the rows.  The xor-shuffle form above goes
+// through the LDS crossbar (ds_bpermute): six dependent round trips per value - the message reverse kernel reduces four
+// values per edge, 96 ds_bpermute per 4-edge chunk before, none now.  Fixed order: deterministic.
+template <int CTRL>
+__device__ __forceinline__ float dpp_mov(float v) {
+  return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xf, 0xf, true));
+}
+__device__ __forceinline__ float wave_sum_uniform(float v) {
+  v += dpp_mov<0xB1>(v);    // quad_perm [1,0,3,2]
+  v += dpp_mov<0x4E>(v);    // quad_perm [2,3,0,1]
+  v += dpp_mov<0x141>(v);   // row_half_mirror
+  v += dpp_mov<0x140>(v);   // row_mirror
+  return (readlane_f(v, 0) + readlane_f(v, 16)) + (readlane_f(v, 32) + readlane_f(v, 48));
+}
+
 // ---------------------------------------------------------------------------------------------------- stage 0
 // Edge continuation of the index pass: EdgeDirectionNormalized (geom.py:331-378, divide_no_nan).
 struct PainnEdgeExtra {
@@ -399,9 +415,9 @@ __global__ __launch_bounds__(256) void painn_message_bwd_kernel(PainnMsgBwdArgs 
               gv[k] += gdv[u][k] * sw2;
               gr[k] = gdv[u][k] * sw3;
             }
-            gd = wave_sum(gd);
+            gd = wave_sum_uniform(gd);
 #pragma unroll
-            for (int k = 0; k < 3; ++k) gr[k] = wave_sum(gr[k]);
+            for (int k = 0; k < 3; ++k) gr[k] = wave_sum_uniform(gr[k]);
             if (lane == 0) {
               if (a.accumulate) {
                 g_d[r] += gd;
