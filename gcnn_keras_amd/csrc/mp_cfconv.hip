@@ -9,8 +9,14 @@
 // reads 4 B (distance) or 4B B (rbf) + 8 B of indices per edge and adds each node row once or twice).
 //
 // Roofline: 2(BF + F^2) + 2F = 38.1 kflop per edge at F=128, B=20 against <= 100 B of compulsory traffic:
-// MFMA-bound (FP32 matrix peak 157.3 TF).  FP32-in/FP32-acc MFMA only (v_mfma_f32_32x32x2_f32) to hold the
-// 1e-5 budget - there is no TF32 on gfx950.
+// MFMA-bound.  FP32 results throughout (the 1e-5 budget; there is no TF32 on gfx950): GEMM1 (K = B + 1) runs on
+// v_mfma_f32_32x32x2_f32; GEMM2 (K = 128, 85 % of the matrix work) runs on the BF16 matrix pipe as an exact FP32
+// emulation - every FP32 operand is split into three bf16 pieces (8 + 8 + 8 mantissa bits: hi = bf16(x),
+// mid = bf16(x - hi), lo = bf16(x - hi - mid), each difference exact in FP32), and the six leading cross products
+// (hi hi, hi mid, mid hi, mid mid, hi lo, lo hi) are accumulated in FP32 by v_mfma_f32_32x32x16_bf16; the three dropped
+// products are below 2^-24 of |a||b|, the rounding of an FP32 product itself.  Measured on a 32x128x128 tile against
+// float64 (scripts/probes/bf16x3_probe.hip): max error 2.55e-7 of the output scale, the FP32 MFMA chain 2.56e-7.
+// Six 32-cycle MFMAs replace eight 64-cycle ones per 16 k: 2.67x the FP32 matrix rate for the same result.
 //
 // Structure (F = 128 fixed; wave64; one wave owns a tile of 32 consecutive edges of the receiver-sorted list):
 //  * W1 (+ its bias as an extra input row) and W2 live in LDS for the whole persistent workgroup.  W1 rows are stored
@@ -48,10 +54,16 @@ namespace {
 
 using floatx16 = __attribute__((ext_vector_type(16))) float;
 using floatx2 = __attribute__((ext_vector_type(2))) float;
+using bf16x8 = __attribute__((ext_vector_type(8))) __bf16;
 
 constexpr int F = 128;          // feature width of the fused kernel
 constexpr int TE = 32;          // edges per wave tile
 constexpr int MAX_KROWS = 34;   // W1 rows in LDS: B inputs + 1 bias row, padded to even (B <= 32)
+// W2 in LDS: three bf16 images (hi, mid, lo pieces) in MFMA-operand order, 16 B per (piece, k block m, column block jb,
+// lane): element i of that entry = piece(W2[f(m, i, hh)][4 c + jb]), f = 32 (m >> 1) + rowmap(8 (m & 1) + i, hh) - the
+// feature that GEMM1's accumulator register (ib = m >> 1, r = 8 (m & 1) + i) holds in lane half hh.
+constexpr int W2_PIECE_FLOATS = F * F / 2;             // 16384 bf16 = 32 KB per piece
+constexpr int W2_IMG_FLOATS = 3 * W2_PIECE_FLOATS;     // 96 KB
 
 __device__ __forceinline__ int rowmap(int r, int hh) { return (r & 3) + 8 * (r >> 2) + 4 * hh; }
 
@@ -73,7 +85,7 @@ __device__ __forceinline__ float ssp_exact(float x) { return mp_softplus(x) - 0.
 struct CfconvArgs {
   const float* x;         // (N, F) sender-side node features
   const float* edge_in;   // GAUSS: dist (M) ; else rbf (M, B)
-  const float* packed;    // mp_cfconv_pack_f32 output: [MAX_KROWS][F] W1|b1 rows, [F][F] W2, [F] b2 (LDS image order)
+  const float* packed;    // mp_cfconv_pack_f32 output: [MAX_KROWS][F] W1|b1 rows, 3 bf16 images of W2, [F] b2 (LDS image order)
   const int32_t* recv;    // (M) receiver ids, ascending (already permuted if perm != null)
   const int32_t* send;    // (M) sender ids in original edge order
   const int32_t* perm;    // (M) sorted position -> original edge, or null
@@ -110,8 +122,8 @@ __global__ __launch_bounds__(WAVES * 64, (WAVES == 4 && COMPACT) ? 2 : 1) void c
   // (22 for B = 20: the workgroup then needs 79.3 KB, so two workgroups - e.g. of two forwards in flight - share a CU)
   constexpr int W1ROWS = NKT > 0 ? 2 * NKT : MAX_KROWS;
   float* W1s = lds;                          // [W1ROWS][F] packed
-  float* W2s = lds + W1ROWS * F;             // [F][F] natural
-  float* Xs = W2s + F * F;                   // [WAVES][2][F] lane-transposition scratch for the boundary atomics
+  float* W2s = lds + W1ROWS * F;             // three bf16 operand images of W2 (W2_IMG_FLOATS)
+  float* Xs = W2s + W2_IMG_FLOATS;           // [WAVES][2][F] lane-transposition scratch for the boundary atomics
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -163,9 +175,9 @@ __global__ __launch_bounds__(WAVES * 64, (WAVES == 4 && COMPACT) ? 2 : 1) void c
   }
   float bias2[4];
 #pragma unroll
-  for (int jb = 0; jb < 4; ++jb) bias2[jb] = a.packed[MAX_KROWS * F + F * F + 4 * c + jb];
+  for (int jb = 0; jb < 4; ++jb) bias2[jb] = a.packed[MAX_KROWS * F + W2_IMG_FLOATS + 4 * c + jb];
   {
-    constexpr int CHUNKS_PER_WAVE = (F * F / 256) / WAVES;  // 1-KB chunks of the W2 image per wave
+    constexpr int CHUNKS_PER_WAVE = (W2_IMG_FLOATS / 256) / WAVES;  // 1-KB chunks of the W2 images per wave
     const float* src = a.packed + MAX_KROWS * F;
 #pragma unroll
     for (int i = 0; i < CHUNKS_PER_WAVE; ++i) {
@@ -179,7 +191,7 @@ __global__ __launch_bounds__(WAVES * 64, (WAVES == 4 && COMPACT) ? 2 : 1) void c
 
   MP_STAMP(0)
   const float* w1_lane = W1s + (nk * hh) * F + 4 * c;  // + s*F           : rows s (lo half) / nk+s (hi half)
-  const float* w2_lane = W2s + (4 * hh) * F + 4 * c;   // + (ib*32 + (r&3) + 8*(r>>2))*F
+  const char* w2_lane = reinterpret_cast<const char*>(W2s) + lane * 16;   // + ((piece * 8 + m) * 4 + jb) * 1024
 
   for (int tile0 = tile_first; tile0 < a.ntiles; tile0 += tile_step) {
     const int tile = __builtin_amdgcn_readfirstlane(tile0);
@@ -275,23 +287,39 @@ __global__ __launch_bounds__(WAVES * 64, (WAVES == 4 && COMPACT) ? 2 : 1) void c
     }
     if constexpr (X_AT == 1) load_sender_rows();
     MP_STAMP(3)
-    // ---- GEMM2: w[e][j] = sum_f h[e][f] W2[f][j] + b2[j]; A = the accumulator registers of GEMM1 ------------
+    // ---- GEMM2: w[e][j] = sum_f h[e][f] W2[f][j] + b2[j]; A = the accumulator registers of GEMM1, split into three
+    //      bf16 pieces per k block (16 features: 8 registers of each lane half); B = the pre-split images in LDS, one
+    //      ds_read_b128 per piece; six v_mfma_f32_32x32x16_bf16 per (k block, column block), smallest products first ----
     floatx16 w[4];
 #pragma unroll
     for (int jb = 0; jb < 4; ++jb)
 #pragma unroll
       for (int r = 0; r < 16; ++r) w[jb][r] = bias2[jb];
 #pragma unroll
-    for (int ib = 0; ib < 4; ++ib) {
+    for (int m = 0; m < 8; ++m) {
+      bf16x8 a_hi, a_mid, a_lo;
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const float4 bv =
-            *reinterpret_cast<const float4*>(w2_lane + (ib * 32 + (r & 3) + 8 * (r >> 2)) * F);
-        const float av = h[ib][r];
-        w[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv.x, w[0], 0, 0, 0);
-        w[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv.y, w[1], 0, 0, 0);
-        w[2] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv.z, w[2], 0, 0, 0);
-        w[3] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv.w, w[3], 0, 0, 0);
+      for (int i = 0; i < 8; ++i) {
+        const float x = h[m >> 1][8 * (m & 1) + i];
+        const __bf16 p0 = static_cast<__bf16>(x);
+        const float r1 = x - static_cast<float>(p0);        // exact: at most 17 significant bits
+        const __bf16 p1 = static_cast<__bf16>(r1);
+        const float r2 = r1 - static_cast<float>(p1);       // exact
+        a_hi[i] = p0;
+        a_mid[i] = p1;
+        a_lo[i] = static_cast<__bf16>(r2);
+      }
+#pragma unroll
+      for (int jb = 0; jb < 4; ++jb) {
+        const bf16x8 b_hi = *reinterpret_cast<const bf16x8*>(w2_lane + ((0 * 8 + m) * 4 + jb) * 1024);
+        const bf16x8 b_mid = *reinterpret_cast<const bf16x8*>(w2_lane + ((1 * 8 + m) * 4 + jb) * 1024);
+        const bf16x8 b_lo = *reinterpret_cast<const bf16x8*>(w2_lane + ((2 * 8 + m) * 4 + jb) * 1024);
+        w[jb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_lo, b_hi, w[jb], 0, 0, 0);
+        w[jb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_hi, b_lo, w[jb], 0, 0, 0);
+        w[jb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_mid, b_mid, w[jb], 0, 0, 0);
+        w[jb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_mid, b_hi, w[jb], 0, 0, 0);
+        w[jb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_hi, b_mid, w[jb], 0, 0, 0);
+        w[jb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_hi, b_hi, w[jb], 0, 0, 0);
       }
     }
 
@@ -416,11 +444,11 @@ __global__ __launch_bounds__(WAVES * 64, (WAVES == 4 && COMPACT) ? 2 : 1) void c
   }
 }
 
-constexpr int PACKED_FLOATS = MAX_KROWS * F + F * F + F;
+constexpr int PACKED_FLOATS = MAX_KROWS * F + W2_IMG_FLOATS + F;
 
 // LDS image of the filter-MLP weights: row k of W1 (k < B), the bias b1 as row B, zero rows up to MAX_KROWS, each row
-// stored [4*c + blk] = W1[k][blk*32 + c]; then W2 and b2 in natural order (lane c of GEMM2 owns output features
-// 4c .. 4c+3, one per accumulator block).
+// stored [4*c + blk] = W1[k][blk*32 + c]; then the three bf16 operand images of W2 (see W2_PIECE_FLOATS; lane c of GEMM2
+// owns output features 4c .. 4c+3, one per accumulator block) and b2 in natural order.
 __global__ void cfconv_pack_kernel(const float* __restrict__ W1, const float* __restrict__ b1, int B,
                                    const float* __restrict__ W2, const float* __restrict__ b2,
                                    float* __restrict__ packed) {
@@ -431,11 +459,28 @@ __global__ void cfconv_pack_kernel(const float* __restrict__ W1, const float* __
       const int k = i / F, col = (i % F) / 4 + 32 * (i % 4);
       if (k < B) v = W1[k * F + col];
       else if (k == B && b1) v = b1[col];
-    } else if (i < MAX_KROWS * F + F * F) {
+    } else if (i < MAX_KROWS * F + W2_IMG_FLOATS) {
+      // one float slot = two consecutive bf16 elements (2 q, 2 q + 1) of an entry
       const int j = i - MAX_KROWS * F;
-      v = W2[j];
+      const int piece = j / W2_PIECE_FLOATS, t = j % W2_PIECE_FLOATS;
+      const int q = t & 3, ln = (t >> 2) & 63, jb = (t >> 8) & 3, m = t >> 10;
+      const int cc = ln & 31, hh = ln >> 5;
+      unsigned bits[2];
+      for (int e = 0; e < 2; ++e) {
+        const int ii = 2 * q + e;
+        const int f = 32 * (m >> 1) + rowmap(8 * (m & 1) + ii, hh);
+        const float x = W2[f * F + 4 * cc + jb];
+        const __bf16 p0 = static_cast<__bf16>(x);
+        const float r1 = x - static_cast<float>(p0);
+        const __bf16 p1 = static_cast<__bf16>(r1);
+        const float r2 = r1 - static_cast<float>(p1);
+        const __bf16 p2 = static_cast<__bf16>(r2);
+        const __bf16 pick = piece == 0 ? p0 : (piece == 1 ? p1 : p2);
+        bits[e] = static_cast<unsigned>(__builtin_bit_cast(unsigned short, pick));
+      }
+      v = __uint_as_float(bits[0] | (bits[1] << 16));
     } else {
-      v = b2 ? b2[i - MAX_KROWS * F - F * F] : 0.0f;
+      v = b2 ? b2[i - MAX_KROWS * F - W2_IMG_FLOATS] : 0.0f;
     }
     packed[i] = v;
   }
@@ -486,7 +531,7 @@ inline int ensure_dynamic_lds(const void* kernel, size_t lds, unsigned long long
 
 template <int WAVES, int NKT>
 size_t cfconv_lds_bytes() {
-  return sizeof(float) * ((NKT > 0 ? 2 * NKT : MAX_KROWS) * F + F * F + WAVES * 2 * F);
+  return sizeof(float) * ((NKT > 0 ? 2 * NKT : MAX_KROWS) * F + W2_IMG_FLOATS + WAVES * 2 * F);
 }
 
 template <int WAVES, bool GAUSS, bool FAST, int NKT, bool DIAG, bool COMPACT = false>
@@ -503,11 +548,7 @@ int launch_cfconv(const CfconvArgs& args, int grid, hipStream_t s) {
 
 template <bool GAUSS, bool FAST>
 int launch_by_basis(const CfconvArgs& args, int waves, int grid, bool compact, hipStream_t s) {
-  if constexpr (GAUSS) {
-    // 256-register build of the 4-wave kernel (sender rows requested before GEMM2 instead of at tile start): two
-    // workgroups fit on a CU, which pays when several forwards are in flight on separate streams.
-    if (waves == 4 && compact && args.B == 20) return launch_cfconv<4, true, FAST, 11, false, true>(args, grid, s);
-  }
+  (void)compact;   // flag bit 4 selects the 8-wave build in cfconv_dispatch (two waves per SIMD on ONE LDS image)
   if (waves == 8) {
     if (args.B == 20) return launch_cfconv<8, GAUSS, FAST, 11, false>(args, grid, s);
     return launch_cfconv<8, GAUSS, FAST, 0, false>(args, grid, s);
@@ -534,7 +575,10 @@ int cfconv_dispatch(CfconvArgs args, bool gauss, int flags, hipStream_t s) {
   int waves = args.ntiles >= 4096 ? 8 : 4;
   if (flags & 4) waves = 8;
   if (flags & 8) waves = 4;
+  // Flag bit 4 ("several forwards in flight"): the weight images take 107-120 KB of LDS, so two workgroups no longer fit
+  // a CU; the second wave per SIMD that fills the first one's vector phases comes from the 8-wave build instead.
   const bool compact = (flags & 16) != 0;
+  if (compact && !(flags & 8)) waves = 8;
   int grid = (args.ntiles + waves - 1) / waves;
   if (grid > 256) grid = 256;
   if (args.diag) {

@@ -9,6 +9,7 @@
 Both go through the C ABI only; there is no CPU path.
 """
 import ctypes
+import os
 
 import torch
 
@@ -75,9 +76,11 @@ class SchnetForward:
         self._streams = []
         self._slots = []
         self.in_flight = max(1, int(in_flight)) if mode == "fused" else 1
-        if mode == "fused" and self.in_flight > 1:
-            # several forwards in flight: the 256-register / 79 KB cfconv build lets two workgroups share a CU
-            self.model.fused.cfconv_flags = 16
+        # several forwards in flight use the same 4-wave cfconv build as a lone forward (flag bit 4 - the 8-wave build,
+        # two waves per SIMD on one LDS image - measured equal within run-to-run spread: 634 vs 621 M edges/s, and it
+        # costs a lone forward 12 us); MPENGINE_INFLIGHT_CFCONV_FLAGS overrides for experiments
+        if mode == "fused" and self.in_flight > 1 and os.environ.get("MPENGINE_INFLIGHT_CFCONV_FLAGS"):
+            self.model.fused.cfconv_flags = int(os.environ["MPENGINE_INFLIGHT_CFCONV_FLAGS"])
         if mode == "fused":
             self.model.fused.max_slots = max(self.model.fused.max_slots, self.in_flight)
 
