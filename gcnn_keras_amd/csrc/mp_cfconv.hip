@@ -295,32 +295,102 @@ __global__ __launch_bounds__(WAVES * 64, (WAVES == 4 && COMPACT) ? 2 : 1) void c
     for (int jb = 0; jb < 4; ++jb)
 #pragma unroll
       for (int r = 0; r < 16; ++r) w[jb][r] = bias2[jb];
+    // The split of k block m + 1 (vector instructions) is spread over the four column blocks of k block m: a bf16 MFMA
+    // holds the SIMD's vector issue for 8 of its 32 cycles, so the splits run in the shadow of the MFMAs instead of in
+    // front of them (9.7 k -> measured cycles per tile with all of a block's splits ahead of its 24 MFMAs).
+    auto split_into = [&](int m, int i, bf16x8& hi, bf16x8& mid, bf16x8& lo) {
+      const float x = h[m >> 1][8 * (m & 1) + i];
+      const __bf16 p0 = static_cast<__bf16>(x);
+      const float r1 = x - static_cast<float>(p0);        // exact: at most 17 significant bits
+      const __bf16 p1 = static_cast<__bf16>(r1);
+      const float r2 = r1 - static_cast<float>(p1);       // exact
+      hi[i] = p0;
+      mid[i] = p1;
+      lo[i] = static_cast<__bf16>(r2);
+    };
+    bf16x8 a_hi, a_mid, a_lo;
 #pragma unroll
-    for (int m = 0; m < 8; ++m) {
-      bf16x8 a_hi, a_mid, a_lo;
+    for (int i = 0; i < 8; ++i) split_into(0, i, a_hi, a_mid, a_lo);
+    if constexpr (WAVES > 4) {
+      // two waves per SIMD: the sibling wave's MFMAs cover this wave's LDS latency, and the 256-register budget has no
+      // room for a second set of B pieces - plain reads, scheduled by the compiler
 #pragma unroll
-      for (int i = 0; i < 8; ++i) {
-        const float x = h[m >> 1][8 * (m & 1) + i];
-        const __bf16 p0 = static_cast<__bf16>(x);
-        const float r1 = x - static_cast<float>(p0);        // exact: at most 17 significant bits
-        const __bf16 p1 = static_cast<__bf16>(r1);
-        const float r2 = r1 - static_cast<float>(p1);       // exact
-        a_hi[i] = p0;
-        a_mid[i] = p1;
-        a_lo[i] = static_cast<__bf16>(r2);
+      for (int m = 0; m < 8; ++m) {
+        bf16x8 n_hi, n_mid, n_lo;
+#pragma unroll
+        for (int jb = 0; jb < 4; ++jb) {
+          const bf16x8 b_hi = *reinterpret_cast<const bf16x8*>(w2_lane + (0 * 32 + 4 * m + jb) * 1024);
+          const bf16x8 b_mid = *reinterpret_cast<const bf16x8*>(w2_lane + (1 * 32 + 4 * m + jb) * 1024);
+          const bf16x8 b_lo = *reinterpret_cast<const bf16x8*>(w2_lane + (2 * 32 + 4 * m + jb) * 1024);
+          w[jb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_lo, b_hi, w[jb], 0, 0, 0);
+          w[jb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_hi, b_lo, w[jb], 0, 0, 0);
+          w[jb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_mid, b_mid, w[jb], 0, 0, 0);
+          w[jb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_mid, b_hi, w[jb], 0, 0, 0);
+          w[jb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_hi, b_mid, w[jb], 0, 0, 0);
+          w[jb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_hi, b_hi, w[jb], 0, 0, 0);
+          if (m < 7) {
+            split_into(m + 1, 2 * jb, n_hi, n_mid, n_lo);
+            split_into(m + 1, 2 * jb + 1, n_hi, n_mid, n_lo);
+          }
+        }
+        a_hi = n_hi;
+        a_mid = n_mid;
+        a_lo = n_lo;
       }
+    } else {
+      // B pieces are read one (k block, column block) step ahead of the MFMAs that consume them.  Left to itself the
+      // compiler (at its register cap) sinks every ds_read_b128 in front of its first MFMA and waits out the LDS latency
+      // there, 2-3 times per step: the reads are therefore issued as volatile asm in program order, and the wait that
+      // publishes them - tied to the destination registers so that no consumer can move above it - closes the step.
+      const unsigned w2_addr = static_cast<unsigned>(reinterpret_cast<size_t>(
+          (__attribute__((address_space(3))) const char*)(w2_lane)));
+      const unsigned w2_addr_mid = w2_addr + 32 * 1024, w2_addr_lo = w2_addr + 64 * 1024;
+#define MP_LDS_B128(dst, addr, t) \
+    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"((t) * 1024))
+      bf16x8 b_hi, b_mid, b_lo;
+      MP_LDS_B128(b_hi, w2_addr, 0);
+      MP_LDS_B128(b_mid, w2_addr_mid, 0);
+      MP_LDS_B128(b_lo, w2_addr_lo, 0);
+      asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(b_hi), "+v"(b_mid), "+v"(b_lo));
 #pragma unroll
-      for (int jb = 0; jb < 4; ++jb) {
-        const bf16x8 b_hi = *reinterpret_cast<const bf16x8*>(w2_lane + ((0 * 8 + m) * 4 + jb) * 1024);
-        const bf16x8 b_mid = *reinterpret_cast<const bf16x8*>(w2_lane + ((1 * 8 + m) * 4 + jb) * 1024);
-        const bf16x8 b_lo = *reinterpret_cast<const bf16x8*>(w2_lane + ((2 * 8 + m) * 4 + jb) * 1024);
-        w[jb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_lo, b_hi, w[jb], 0, 0, 0);
-        w[jb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_hi, b_lo, w[jb], 0, 0, 0);
-        w[jb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_mid, b_mid, w[jb], 0, 0, 0);
-        w[jb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_mid, b_hi, w[jb], 0, 0, 0);
-        w[jb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_hi, b_mid, w[jb], 0, 0, 0);
-        w[jb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_hi, b_hi, w[jb], 0, 0, 0);
+      for (int m = 0; m < 8; ++m) {
+        bf16x8 n_hi, n_mid, n_lo;
+#pragma unroll
+        for (int jb = 0; jb < 4; ++jb) {
+          bf16x8 c_hi, c_mid, c_lo;
+          if (4 * m + jb + 1 < 32) {
+            // (the accumulator operand orders the reads AHEAD of this step's MFMAs; nothing touches it)
+#define MP_READ_NEXT_B(ACC)                                                                                                \
+    asm volatile("ds_read_b128 %0, %3 offset:%6\n\tds_read_b128 %1, %4 offset:%6\n\tds_read_b128 %2, %5 offset:%6"            \
+                 : "=&v"(c_hi), "=&v"(c_mid), "=&v"(c_lo)                                                                    \
+                 : "v"(w2_addr), "v"(w2_addr_mid), "v"(w2_addr_lo), "n"((4 * m + jb + 1) * 1024), ACC(w[jb]));             \
+    asm volatile("" : "+" ACC(w[jb]));
+            MP_READ_NEXT_B("a")
+#undef MP_READ_NEXT_B
+          }
+          w[jb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_lo, b_hi, w[jb], 0, 0, 0);
+          w[jb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_hi, b_lo, w[jb], 0, 0, 0);
+          w[jb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_mid, b_mid, w[jb], 0, 0, 0);
+          w[jb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_mid, b_hi, w[jb], 0, 0, 0);
+          w[jb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_hi, b_mid, w[jb], 0, 0, 0);
+          w[jb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_hi, b_hi, w[jb], 0, 0, 0);
+          if (m < 7) {
+            split_into(m + 1, 2 * jb, n_hi, n_mid, n_lo);
+            split_into(m + 1, 2 * jb + 1, n_hi, n_mid, n_lo);
+          }
+          if (4 * m + jb + 1 < 32) {
+            // the accumulator operand only orders this wait behind the step's MFMAs (nothing reads it)
+            asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(c_hi), "+v"(c_mid), "+v"(c_lo), "+a"(w[jb]));
+            b_hi = c_hi;
+            b_mid = c_mid;
+            b_lo = c_lo;
+          }
+        }
+        a_hi = n_hi;
+        a_mid = n_mid;
+        a_lo = n_lo;
       }
+#undef MP_LDS_B128
     }
 
     MP_STAMP(4)

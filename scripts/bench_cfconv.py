@@ -8,7 +8,7 @@ if os.environ.get("MP_LIB"):  # A/B runs of two builds of the engine on the same
 from gcnn_keras_amd.engine import _HipTimer
 from gcnn_keras_amd.fused import FusedSchnet
 
-def run(graphs, flags_list=(1, 5), iters=100):
+def run(graphs, flags_list=(1, 5, 9), iters=100):
     b = synth.qm9_like_batch(num_graphs=graphs, seed=1234)
     p = synth.schnet_params(seed=7)
     for fl in flags_list:
