@@ -645,11 +645,13 @@ int cfconv_dispatch(CfconvArgs args, bool gauss, int flags, hipStream_t s) {
   int waves = args.ntiles >= 4096 ? 8 : 4;
   if (flags & 4) waves = 8;
   if (flags & 8) waves = 4;
-  // Flag bit 4 ("several forwards in flight"): the weight images take 107-120 KB of LDS, so two workgroups no longer fit
-  // a CU; the second wave per SIMD that fills the first one's vector phases comes from the 8-wave build instead.
+  // Flag bit 4 ("several forwards in flight"): every workgroup claims a whole CU (all its registers, 107-120 KB of LDS), so
+  // forwards of different batches share the GPU only CU by CU; with this flag a launch uses half as many workgroups, two
+  // tiles per wave - the per-workgroup fixed cost (launch ramp, 107 KB of weight staging) is paid once per eight tiles
+  // and the other half of the CUs is free for the other batches' kernels.  Costs a lone launch latency; not the default.
   const bool compact = (flags & 16) != 0;
-  if (compact && !(flags & 8)) waves = 8;
   int grid = (args.ntiles + waves - 1) / waves;
+  if (compact && grid > 1) grid = (grid + 1) / 2;
   if (grid > 256) grid = 256;
   if (args.diag) {
     MP_REQUIRE(gauss && args.B == 20, "mp_cfconv: the diagnostic build exists for the 20-bin Gauss variant only");

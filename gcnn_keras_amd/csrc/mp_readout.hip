@@ -24,9 +24,20 @@ __global__ __launch_bounds__(256) void pool_mlp2_kernel(const float* __restrict_
                                                         float* __restrict__ out, float* __restrict__ g_x) {
   constexpr int K = 64 * NK, H = 64 * NH;
   __shared__ float Ws[K * H];
-  for (int i = threadIdx.x; i < K * H; i += 256) {
-    const int k = i / H, c = i % H;
-    Ws[k * H + (c ^ (k & 31))] = W0[i];
+  // 16-B global loads (all of a thread's requests in flight at once), swizzled scalar LDS stores
+  constexpr int NV4 = K * H / 4 / 256;
+  float4 stage[NV4];
+#pragma unroll
+  for (int j = 0; j < NV4; ++j) stage[j] = reinterpret_cast<const float4*>(W0)[threadIdx.x + j * 256];
+#pragma unroll
+  for (int j = 0; j < NV4; ++j) {
+    const int i = 4 * (threadIdx.x + j * 256);
+    const int k = i / H, c = i % H;            // c % 4 == 0: the four columns stay inside one aligned group of 32
+    float* row = Ws + k * H;
+    row[(c + 0) ^ (k & 31)] = stage[j].x;
+    row[(c + 1) ^ (k & 31)] = stage[j].y;
+    row[(c + 2) ^ (k & 31)] = stage[j].z;
+    row[(c + 3) ^ (k & 31)] = stage[j].w;
   }
   const int lane = threadIdx.x & 63;
   float b0v[NH], w1v[NH];

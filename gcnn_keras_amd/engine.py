@@ -123,7 +123,7 @@ class SchnetForward:
         if self.in_flight > 1:
             self._place_streams()
 
-    def _place_streams(self, draws=4, steps=120):
+    def _place_streams(self, draws=8, steps=150):
         """How well forwards in flight overlap depends on which hardware queues the streams land on (the ROCm runtime
         multiplexes streams onto a few queues; a stream sharing a queue with another serialises behind it: measured 48 vs
         64 us per step for different draws of four streams from torch's pool).  This draws the streams a few times,

@@ -38,7 +38,7 @@ def _cfconv_case(seed, num_graphs=9, shuffle=False):
 
 @pytest.mark.parametrize("shuffle", [False, True])
 @pytest.mark.parametrize("variant", ["rbf", "gauss"])
-@pytest.mark.parametrize("fast", [0, 1, 4, 5, 17])   # bit0: fast softplus, bit2: 8-wave workgroup, bit4: 256-register build
+@pytest.mark.parametrize("fast", [0, 1, 4, 5, 17])   # bit0: fast softplus, bit2: 8-wave workgroup, bit4: half the workgroups
 def test_cfconv_fused_vs_oracle(shuffle, variant, fast):
     from gcnn_keras_amd import _ffi
     from gcnn_keras_amd.ragged import RaggedTensor
@@ -70,6 +70,51 @@ def test_cfconv_fused_vs_oracle(shuffle, variant, fast):
     got = out.cpu().numpy()
     assert _rel_err(got, ref) <= 1e-5                       # north_star tolerance for the float segment-sum
     assert _rel_err(got, ref64) <= max(4 * _rel_err(ref, ref64), 2e-6)
+
+
+@pytest.mark.parametrize("flags", [0, 4])
+@pytest.mark.parametrize("case", ["wide_range", "cancellation", "tiny"])
+def test_cfconv_split_precision_gemm_keeps_the_fp32_error_budget(case, flags):
+    """GEMM2 of the kernel runs on the bf16 matrix pipe as an FP32 emulation (three bf16 pieces per operand, six products,
+    FP32 accumulate).  Inputs chosen against that scheme: second-layer weights spanning nine orders of magnitude in one
+    column, columns that cancel to ~1e-4 of their terms, and weights near the bottom of the normal range.  The bar is
+    the float32 NumPy oracle's own distance from its float64 twin (x4), i.e. the kernel may not be measurably worse than a
+    k-ordered FP32 fma chain - plus the 1e-5 north-star bar against the float32 oracle."""
+    from gcnn_keras_amd import _ffi
+    from gcnn_keras_amd.ragged import RaggedTensor
+    b, x, ridx, dist, rbf, p = _cfconv_case(33)
+    rng = np.random.default_rng(5)
+    p = {k: v.copy() for k, v in p.items()}
+    w2 = p["dense2/kernel"]
+    if case == "wide_range":
+        w2 *= (10.0 ** rng.uniform(-6, 3, size=w2.shape)).astype(np.float32)
+    elif case == "cancellation":      # rows pair up with opposite signs and nearly equal magnitude
+        w2[1::2] = -w2[0::2] * (1.0 + 1e-4 * rng.standard_normal(w2[0::2].shape)).astype(np.float32)
+        p["dense1/kernel"][:, 1::2] = p["dense1/kernel"][:, 0::2]
+        p["dense1/bias"][1::2] = p["dense1/bias"][0::2]
+    else:
+        w2 *= np.float32(1e-30)
+        p["dense2/bias"] *= np.float32(1e-30)
+    ref = ko.schnet_cfconv(x, rbf, ridx, p).values
+    ref64 = ko.schnet_cfconv(ko.to_dtype(x, np.float64), ko.to_dtype(rbf, np.float64), ridx,
+                             ko.to_dtype(p, np.float64)).values
+    dx = RaggedTensor.from_numpy(x.values, x.row_splits)
+    di = RaggedTensor.from_numpy(ridx.values, ridx.row_splits)
+    plan = di.index_plan(dx)
+    _, perm, seg = plan.csr(0)
+    out = torch.zeros((plan.N, 128), dtype=torch.float32, device="cuda")
+    w = {k: torch.from_numpy(v).cuda() for k, v in p.items()}
+    packed = torch.empty(_ffi.lib().mp_cfconv_packed_floats(), dtype=torch.float32, device="cuda")
+    _ffi.call("mp_cfconv_pack_f32", _ffi.ptr(w["dense1/kernel"]), _ffi.ptr(w["dense1/bias"]), 20,
+              _ffi.ptr(w["dense2/kernel"]), _ffi.ptr(w["dense2/bias"]), _ffi.ptr(packed), _ffi.stream())
+    e = torch.from_numpy(rbf.values).cuda()
+    _ffi.call("mp_cfconv_fused_f32", _ffi.ptr(dx.values), plan.N, _ffi.ptr(e), 20, _ffi.ptr(packed),
+              _ffi.ptr(seg.contiguous()), _ffi.ptr(plan.col(1).contiguous()), _ffi.ptr(perm), plan.M, flags, _ffi.ptr(out),
+              _ffi.stream())
+    got = out.cpu().numpy()
+    oracle_err = _rel_err(ref, ref64)
+    assert _rel_err(got, ref64) <= max(4 * oracle_err, 2e-6), (case, _rel_err(got, ref64), oracle_err)
+    assert _rel_err(got, ref) <= max(1e-5, 8 * oracle_err)
 
 
 @pytest.mark.parametrize("flags", [1, 5, 17])
