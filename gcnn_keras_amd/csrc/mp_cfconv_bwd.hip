@@ -12,9 +12,13 @@
 //               GH = W2 v^T (128 x 128 x 32, the same 256 MFMAs as the forward's GEMM2), then an in-register
 //               contraction over the 128 hidden features and one cross-half shuffle.
 //
-// FP32 MFMA (v_mfma_f32_32x32x2_f32) as in the forward.  LDS per workgroup: W1 image (34 rows, the forward's packing), W2
-// re-packed for the A operand (W2p[j][4c+ib] = W2[32 ib + c][j]: one ds_read_b128 feeds four MFMAs), and one 32 x 128
-// tile of v per wave (row stride 129: the B-operand reads of a half wave hit 32 different banks).
+// P and Z (K = B + 1) run on v_mfma_f32_32x32x2_f32.  GH (K = 128, 70 % of the matrix work) runs on the bf16 matrix pipe
+// as the exact FP32 emulation of the forward kernel (csrc/mp_cfconv.hip: three bf16 pieces per operand, six products,
+// FP32 accumulate): W2's pieces come pre-split from the image (A operand, one ds_read_b128 per piece), v is built in
+// REGISTERS - lane (edge e, k half) loads the 8 features of g_out[recv(e)] and x[send(e)] that are its k slots of the
+// current k block, multiplies and splits them - so the (32 x 128) v tile of the FP32 build (66 KB of LDS per workgroup,
+// a store and a strided read per element) is gone.  LDS per workgroup: W1 image (34 rows, the forward's packing) + the
+// three W2 images = 113 KB.
 #include <mutex>
 
 #include "mp_common.h"
@@ -22,13 +26,17 @@
 namespace {
 
 using floatx16 = __attribute__((ext_vector_type(16))) float;
+using bf16x8 = __attribute__((ext_vector_type(8))) __bf16;
 
 constexpr int F = 128;
 constexpr int TE = 32;
 constexpr int MAX_KROWS = 34;   // W1 rows in LDS: B inputs + 1 bias row, padded to even (B <= 32)
-constexpr int V_LD = 129;
 constexpr int WAVES = 4;
-constexpr int PACKED_BWD_FLOATS = MAX_KROWS * F + F * F;
+// W2 as A operand of v_mfma_f32_32x32x16_bf16: 16 B per (piece, k block kb, row block ib, lane): element i =
+// piece(W2[32 ib + (lane & 31)][16 kb + 8 (lane >> 5) + i])
+constexpr int W2_PIECE_FLOATS = F * F / 2;
+constexpr int W2_IMG_FLOATS = 3 * W2_PIECE_FLOATS;
+constexpr int PACKED_BWD_FLOATS = MAX_KROWS * F + W2_IMG_FLOATS;
 
 struct CfconvBwdArgs {
   const float* x;        // (N, F) sender-side node features of the block (forward input)
@@ -48,8 +56,7 @@ struct CfconvBwdArgs {
 __global__ __launch_bounds__(WAVES * 64, 1) void cfconv_dist_grad_kernel(CfconvBwdArgs a) {
   extern __shared__ __align__(16) float lds[];
   float* W1s = lds;                        // [MAX_KROWS][F] packed like the forward
-  float* W2s = lds + MAX_KROWS * F;        // [F][F]: W2s[j][4c + ib] = W2[32 ib + c][j]
-  float* Vs = W2s + F * F;                 // [WAVES][TE][V_LD]
+  float* W2s = lds + MAX_KROWS * F;        // three bf16 operand images of W2
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -64,9 +71,10 @@ __global__ __launch_bounds__(WAVES * 64, 1) void cfconv_dist_grad_kernel(CfconvB
     for (int i = tid; i < PACKED_BWD_FLOATS / 4; i += WAVES * 64) dst[i] = src[i];
   }
   __syncthreads();
-  float* Vw = Vs + wave * TE * V_LD;
   const float* w1_lane = W1s + (nk * hh) * F + 4 * c;   // + s*F : rows s (low half) / nk + s (high half)
-  const float* w2_lane = W2s + hh * F + 4 * c;          // + 2s*F: row j = 2s + hh
+  const unsigned w2_addr = static_cast<unsigned>(reinterpret_cast<size_t>(
+      (__attribute__((address_space(3))) const char*)(reinterpret_cast<const char*>(W2s) + lane * 16)));
+  const unsigned w2_addr_mid = w2_addr + 32 * 1024, w2_addr_lo = w2_addr + 64 * 1024;
   const float fbins = static_cast<float>(B);
 
   // XCD-aware block order (mp_common.h): consecutive edge tiles share one XCD's L2
@@ -80,21 +88,14 @@ __global__ __launch_bounds__(WAVES * 64, 1) void cfconv_dist_grad_kernel(CfconvB
     const int my_send = a.send[ec];
     const float d = a.dist[ec];
 
-    // ---- v tile into LDS: v[e][k] = g_out[recv(e)][k] * x[send(e)][k]; a half wave reads one whole 512-B row -------------
-#pragma unroll 4
-    for (int it = 0; it < TE / 2; ++it) {
-      const int r = 2 * it + hh;
-      int i = __shfl(my_recv, r, 64), j = __shfl(my_send, r, 64);
-      i = i < 0 ? 0 : (i >= a.N ? static_cast<int>(a.N) - 1 : i);
-      j = j < 0 ? 0 : (j >= a.N ? static_cast<int>(a.N) - 1 : j);
-      const float4 g = *reinterpret_cast<const float4*>(a.g_out + static_cast<int64_t>(i) * F + 4 * c);
-      const float4 xv = *reinterpret_cast<const float4*>(a.x + static_cast<int64_t>(j) * F + 4 * c);
-      float* dst = Vw + r * V_LD + 4 * c;
-      dst[0] = g.x * xv.x;
-      dst[1] = g.y * xv.y;
-      dst[2] = g.z * xv.z;
-      dst[3] = g.w * xv.w;
-    }
+    const int i_node = my_recv < 0 ? 0 : (my_recv >= a.N ? static_cast<int>(a.N) - 1 : my_recv);
+    const int j_node = my_send < 0 ? 0 : (my_send >= a.N ? static_cast<int>(a.N) - 1 : my_send);
+    // this lane's k slots of k block kb: features 16 kb + 8 hh + (0..7) of its edge's two rows (32 B each)
+    const float4* g_row = reinterpret_cast<const float4*>(a.g_out + static_cast<int64_t>(i_node) * F + 8 * hh);
+    const float4* x_row = reinterpret_cast<const float4*>(a.x + static_cast<int64_t>(j_node) * F + 8 * hh);
+    float4 gq[2][2], xq[2][2];           // [buffer][first / second four features]
+    gq[0][0] = g_row[0]; gq[0][1] = g_row[1];
+    xq[0][0] = x_row[0]; xq[0][1] = x_row[1];
 
     // ---- P = pre1^T (with bias row) and Z = (g'(d) W1)^T: B operands are this lane's half of its edge's basis row ----
     floatx16 P[4], Z[4];
@@ -128,21 +129,61 @@ __global__ __launch_bounds__(WAVES * 64, 1) void cfconv_dist_grad_kernel(CfconvB
 #pragma unroll
       for (int r = 0; r < 16; ++r) P[ib][r] = Z[ib][r] / (1.0f + expf(-P[ib][r]));
 
-    // ---- GH[h][e] = sum_j W2[h][j] v[e][j]: A from the W2 image (row j = 2s + hh), B from this wave's v tile -----------
+    // ---- GH[h][e] = sum_j W2[h][j] v[e][j] on the bf16 pipe: A = W2 pieces from LDS (read one step ahead, asm-ordered
+    //      against the MFMAs as in the forward kernel), B = this lane's eight v values of the k block, split in registers ----
     floatx16 GH[4];
 #pragma unroll
     for (int ib = 0; ib < 4; ++ib)
 #pragma unroll
       for (int r = 0; r < 16; ++r) GH[ib][r] = 0.0f;
-    const float* v_lane = Vw + c * V_LD + hh;           // + 2s
-#pragma unroll 8
-    for (int s = 0; s < F / 2; ++s) {
-      const float4 av = *reinterpret_cast<const float4*>(w2_lane + 2 * s * F);
-      const float bv = v_lane[2 * s];
-      GH[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.x, bv, GH[0], 0, 0, 0);
-      GH[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.y, bv, GH[1], 0, 0, 0);
-      GH[2] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.z, bv, GH[2], 0, 0, 0);
-      GH[3] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.w, bv, GH[3], 0, 0, 0);
+    bf16x8 a_hi, a_mid, a_lo;
+    asm volatile("ds_read_b128 %0, %3\n\tds_read_b128 %1, %4\n\tds_read_b128 %2, %5\n\ts_waitcnt lgkmcnt(0)"
+                 : "=&v"(a_hi), "=&v"(a_mid), "=&v"(a_lo) : "v"(w2_addr), "v"(w2_addr_mid), "v"(w2_addr_lo));
+#pragma unroll
+    for (int kb = 0; kb < 8; ++kb) {
+      if (kb + 1 < 8) {   // next k block's rows, in flight during this block's MFMAs
+        gq[(kb + 1) & 1][0] = g_row[4 * (kb + 1)];
+        gq[(kb + 1) & 1][1] = g_row[4 * (kb + 1) + 1];
+        xq[(kb + 1) & 1][0] = x_row[4 * (kb + 1)];
+        xq[(kb + 1) & 1][1] = x_row[4 * (kb + 1) + 1];
+      }
+      const float4 g0 = gq[kb & 1][0], g1 = gq[kb & 1][1], x0 = xq[kb & 1][0], x1 = xq[kb & 1][1];
+      const float vv[8] = {g0.x * x0.x, g0.y * x0.y, g0.z * x0.z, g0.w * x0.w,
+                           g1.x * x1.x, g1.y * x1.y, g1.z * x1.z, g1.w * x1.w};
+      bf16x8 b_hi, b_mid, b_lo;
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        const float xval = valid ? vv[i] : 0.0f;
+        const __bf16 p0 = static_cast<__bf16>(xval);
+        const float r1 = xval - static_cast<float>(p0);
+        const __bf16 p1 = static_cast<__bf16>(r1);
+        const float r2 = r1 - static_cast<float>(p1);
+        b_hi[i] = p0;
+        b_mid[i] = p1;
+        b_lo[i] = static_cast<__bf16>(r2);
+      }
+#pragma unroll
+      for (int ib = 0; ib < 4; ++ib) {
+        bf16x8 n_hi, n_mid, n_lo;
+        if (4 * kb + ib + 1 < 32) {
+          asm volatile("ds_read_b128 %0, %3 offset:%6\n\tds_read_b128 %1, %4 offset:%6\n\tds_read_b128 %2, %5 offset:%6"
+                       : "=&v"(n_hi), "=&v"(n_mid), "=&v"(n_lo)
+                       : "v"(w2_addr), "v"(w2_addr_mid), "v"(w2_addr_lo), "n"((4 * kb + ib + 1) * 1024), "a"(GH[ib]));
+          asm volatile("" : "+a"(GH[ib]));
+        }
+        GH[ib] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_lo, b_hi, GH[ib], 0, 0, 0);
+        GH[ib] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_hi, b_lo, GH[ib], 0, 0, 0);
+        GH[ib] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_mid, b_mid, GH[ib], 0, 0, 0);
+        GH[ib] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_mid, b_hi, GH[ib], 0, 0, 0);
+        GH[ib] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_hi, b_mid, GH[ib], 0, 0, 0);
+        GH[ib] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_hi, b_hi, GH[ib], 0, 0, 0);
+        if (4 * kb + ib + 1 < 32) {
+          asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(n_hi), "+v"(n_mid), "+v"(n_lo), "+a"(GH[ib]));
+          a_hi = n_hi;
+          a_mid = n_mid;
+          a_lo = n_lo;
+        }
+      }
     }
     // ---- contraction over the 128 hidden features: 64 in this lane's registers, 64 in the other half's ----------------
     float part = 0.0f;
@@ -159,7 +200,7 @@ __global__ __launch_bounds__(WAVES * 64, 1) void cfconv_dist_grad_kernel(CfconvB
 }
 
 // Image for the kernel above: W1 rows exactly as mp_cfconv_pack_f32 stores them (row k at [4c + blk] = W1[k][32 blk + c],
-// bias as row B), then W2p[j][4c + ib] = W2[32 ib + c][j].
+// bias as row B), then the three bf16 operand images of W2 (see W2_PIECE_FLOATS).
 __global__ void cfconv_bwd_pack_kernel(const float* __restrict__ W1, const float* __restrict__ b1, int B,
                                        const float* __restrict__ W2, float* __restrict__ packed) {
   const int stride = gridDim.x * blockDim.x;
@@ -169,10 +210,23 @@ __global__ void cfconv_bwd_pack_kernel(const float* __restrict__ W1, const float
       const int k = i / F, col = (i % F) / 4 + 32 * (i % 4);
       if (k < B) v = W1[k * F + col];
       else if (k == B && b1) v = b1[col];
-    } else {
-      const int t = i - MAX_KROWS * F;
-      const int j = t / F, cc = (t % F) / 4, ib = t % 4;
-      v = W2[(32 * ib + cc) * F + j];
+    } else {   // one float slot = two consecutive bf16 elements (2 q, 2 q + 1) of an entry
+      const int j = i - MAX_KROWS * F;
+      const int piece = j / W2_PIECE_FLOATS, t = j % W2_PIECE_FLOATS;
+      const int q = t & 3, ln = (t >> 2) & 63, ib = (t >> 8) & 3, kb = t >> 10;
+      const int hl = ln & 31, kh = ln >> 5;
+      unsigned bits[2];
+      for (int e = 0; e < 2; ++e) {
+        const float x = W2[(32 * ib + hl) * F + 16 * kb + 8 * kh + 2 * q + e];
+        const __bf16 p0 = static_cast<__bf16>(x);
+        const float r1 = x - static_cast<float>(p0);
+        const __bf16 p1 = static_cast<__bf16>(r1);
+        const float r2 = r1 - static_cast<float>(p1);
+        const __bf16 p2 = static_cast<__bf16>(r2);
+        const __bf16 pick = piece == 0 ? p0 : (piece == 1 ? p1 : p2);
+        bits[e] = static_cast<unsigned>(__builtin_bit_cast(unsigned short, pick));
+      }
+      v = __uint_as_float(bits[0] | (bits[1] << 16));
     }
     packed[i] = v;
   }
@@ -206,7 +260,7 @@ int mp_cfconv_gauss_dist_grad_f32(const float* x, const float* g_out, int64_t N,
   a.g_gamma = static_cast<float>(1.0 / static_cast<double>(sigma) / static_cast<double>(sigma) / 2.0);
   a.g_offset = offset;
   a.ntiles = static_cast<int>((M + TE - 1) / TE);
-  const size_t lds = sizeof(float) * (MAX_KROWS * F + F * F + WAVES * TE * V_LD);
+  const size_t lds = sizeof(float) * (MAX_KROWS * F + W2_IMG_FLOATS);
   static std::mutex mu;                      // dynamic-LDS opt-in: per device, guarded
   static unsigned long long done_mask = 0;
   {
