@@ -64,6 +64,12 @@ constexpr int MAX_KROWS = 34;   // W1 rows in LDS: B inputs + 1 bias row, padded
 // feature that GEMM1's accumulator register (ib = m >> 1, r = 8 (m & 1) + i) holds in lane half hh.
 constexpr int W2_PIECE_FLOATS = F * F / 2;             // 16384 bf16 = 32 KB per piece
 constexpr int W2_IMG_FLOATS = 3 * W2_PIECE_FLOATS;     // 96 KB
+// W1 (+ bias row) as bf16 pieces for GEMM1 on the bf16 pipe (basis sizes whose 2 nk <= 32 slots fit two k blocks of 16):
+// 16 B per (piece, k block kb, hidden block ib, lane): element i = piece(W1ext[k][32 ib + c]) with s = 8 kb + i,
+// k = s + nk hh for s < nk (the k assignment of the FP32 build: lane half hh holds rows nk hh .. nk hh + nk - 1), zero
+// beyond; W1ext = W1 rows, then b1, then zeros.
+constexpr int W1B_FLOATS = 3 * 2 * 4 * 64 * 4;         // 24 KB
+constexpr int G1B_MAX_NK = 16;
 
 __device__ __forceinline__ int rowmap(int r, int hh) { return (r & 3) + 8 * (r >> 2) + 4 * hh; }
 
@@ -120,9 +126,11 @@ __global__ __launch_bounds__(WAVES * 64, (WAVES == 4 && COMPACT) ? 2 : 1) void c
   extern __shared__ __align__(16) float lds[];
   // rows of W1 kept in LDS: all MAX_KROWS in the generic build, the 2 nk that GEMM1 reads when the basis size is fixed
   // (22 for B = 20: the workgroup then needs 79.3 KB, so two workgroups - e.g. of two forwards in flight - share a CU)
+  constexpr bool G1B = NKT > 0 && NKT <= G1B_MAX_NK;   // GEMM1 on the bf16 pipe (three pieces per operand, like GEMM2)
   constexpr int W1ROWS = NKT > 0 ? 2 * NKT : MAX_KROWS;
-  float* W1s = lds;                          // [W1ROWS][F] packed
-  float* W2s = lds + W1ROWS * F;             // three bf16 operand images of W2 (W2_IMG_FLOATS)
+  constexpr int W1_LDS_FLOATS = G1B ? W1B_FLOATS : W1ROWS * F;
+  float* W1s = lds;                          // [W1ROWS][F] packed, or the bf16 piece image (W1B_FLOATS)
+  float* W2s = lds + W1_LDS_FLOATS;          // three bf16 operand images of W2 (W2_IMG_FLOATS)
   float* Xs = W2s + W2_IMG_FLOATS;           // [WAVES][2][F] lane-transposition scratch for the boundary atomics
 
   const int tid = threadIdx.x;
@@ -162,21 +170,24 @@ __global__ __launch_bounds__(WAVES * 64, (WAVES == 4 && COMPACT) ? 2 : 1) void c
   };
   prefetch_tile(tile_first);
 
-  // ---- stage the pre-packed weights once per workgroup.  The small W1 image (11-17 KB) goes through registers; the
-  //      64 KB of W2 follow by LDS-DMA (global_load_lds_dwordx4: 1 KB per wave instruction, no VGPRs), issued after the
-  //      W1 loads have been consumed (vmcnt retires in order: an ordinary load waiting behind the DMA would wait for all
-  //      of it).  Neither is awaited here: the barrier that publishes W1 sits right before the first GEMM1 and the one
-  //      that publishes W2 right before the first GEMM2, so the first tile's index wait, sender shuffles and Gauss basis
-  //      run while the other waves' stores and the DMA are still in flight. ------------------------------------------------
-  {
-    const float4* src = reinterpret_cast<const float4*>(a.packed);
-    float4* dst = reinterpret_cast<float4*>(lds);
-    for (int i = tid; i < (W1ROWS * F) / 4; i += WAVES * 64) dst[i] = src[i];
-  }
+  // ---- stage the pre-packed weights once per workgroup, all of them by LDS-DMA (global_load_lds_dwordx4: 1 KB per wave
+  //      instruction, no VGPRs, nothing to wait for here): the W1 image first, then the three W2 images.  (Round 1 sent
+  //      W1 through registers in a rolled load -> wait -> ds_write loop: three serial round trips to L2 before the first
+  //      tile could start.)  The one barrier that publishes the weights sits right before the first GEMM1. ----------------
   float bias2[4];
 #pragma unroll
   for (int jb = 0; jb < 4; ++jb) bias2[jb] = a.packed[MAX_KROWS * F + W2_IMG_FLOATS + 4 * c + jb];
   {
+    constexpr int W1_CHUNKS = W1_LDS_FLOATS / 256;
+    static_assert(W1_LDS_FLOATS % 256 == 0, "the W1 image is staged in 1-KB chunks");
+    const float* src1 = a.packed + (G1B ? MAX_KROWS * F + W2_IMG_FLOATS + F : 0);
+#pragma unroll
+    for (int i = 0; i < (W1_CHUNKS + WAVES - 1) / WAVES; ++i) {
+      const int chunk = i * WAVES + wave;
+      if (chunk < W1_CHUNKS)
+        __builtin_amdgcn_global_load_lds(src1 + chunk * 256 + lane * 4,
+                                         (__attribute__((address_space(3))) void*)(W1s + chunk * 256), 16, 0, 0);
+    }
     constexpr int CHUNKS_PER_WAVE = (W2_IMG_FLOATS / 256) / WAVES;  // 1-KB chunks of the W2 images per wave
     const float* src = a.packed + MAX_KROWS * F;
 #pragma unroll
@@ -186,8 +197,7 @@ __global__ __launch_bounds__(WAVES * 64, (WAVES == 4 && COMPACT) ? 2 : 1) void c
                                        (__attribute__((address_space(3))) void*)(W2s + chunk * 256), 16, 0, 0);
     }
   }
-  bool w1_ready = false;  // wave-uniform: every wave passes each publishing barrier exactly once, W1's before W2's
-  bool w2_ready = false;
+  bool w_ready = false;  // wave-uniform: every wave passes the publishing barrier exactly once
 
   MP_STAMP(0)
   const float* w1_lane = W1s + (nk * hh) * F + 4 * c;  // + s*F           : rows s (lo half) / nk+s (hi half)
@@ -254,9 +264,10 @@ __global__ __launch_bounds__(WAVES * 64, (WAVES == 4 && COMPACT) ? 2 : 1) void c
       }
     }
 
-    if (!w1_ready) {
-      __syncthreads();  // all four waves' parts of W1 are in LDS
-      w1_ready = true;
+    if (!w_ready) {
+      __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0): this wave's share of the weight DMA has landed
+      __syncthreads();                     // ... and so has every other wave's
+      w_ready = true;
     }
     MP_STAMP(1)
     // ---- GEMM1 (transposed): hT[f][e] = sum_k W1p[k][f] * rb[e][k]; lane = edge, register = feature ---------
@@ -265,39 +276,38 @@ __global__ __launch_bounds__(WAVES * 64, (WAVES == 4 && COMPACT) ? 2 : 1) void c
     for (int ib = 0; ib < 4; ++ib)
 #pragma unroll
       for (int r = 0; r < 16; ++r) h[ib][r] = 0.0f;
-#pragma unroll
-    for (int s = 0; s < NKMAX; ++s) {
-      if (s < nk) {
-        const float4 wv = *reinterpret_cast<const float4*>(w1_lane + s * F);
-        h[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(wv.x, rb[s], h[0], 0, 0, 0);
-        h[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(wv.y, rb[s], h[1], 0, 0, 0);
-        h[2] = __builtin_amdgcn_mfma_f32_32x32x2f32(wv.z, rb[s], h[2], 0, 0, 0);
-        h[3] = __builtin_amdgcn_mfma_f32_32x32x2f32(wv.w, rb[s], h[3], 0, 0, 0);
-      }
-    }
-    MP_STAMP(2)
-#pragma unroll
-    for (int ib = 0; ib < 4; ++ib)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) h[ib][r] = FAST_SSP ? ssp_fast(h[ib][r]) : ssp_exact(h[ib][r]);
-
-    if (!w2_ready) {
-      __syncthreads();  // drains this wave's LDS-DMA (vmcnt) and publishes all four waves' parts of W2
-      w2_ready = true;
-    }
-    if constexpr (X_AT == 1) load_sender_rows();
-    MP_STAMP(3)
-    // ---- GEMM2: w[e][j] = sum_f h[e][f] W2[f][j] + b2[j]; A = the accumulator registers of GEMM1, split into three
-    //      bf16 pieces per k block (16 features: 8 registers of each lane half); B = the pre-split images in LDS, one
-    //      ds_read_b128 per piece; six v_mfma_f32_32x32x16_bf16 per (k block, column block), smallest products first ----
-    floatx16 w[4];
+    floatx16 w[4];   // GEMM2's accumulators: w[jb][r] = filter value of edge row r, feature 4 c + jb (b2 joins in the walk)
 #pragma unroll
     for (int jb = 0; jb < 4; ++jb)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) w[jb][r] = bias2[jb];
-    // The split of k block m + 1 (vector instructions) is spread over the four column blocks of k block m: a bf16 MFMA
-    // holds the SIMD's vector issue for 8 of its 32 cycles, so the splits run in the shadow of the MFMAs instead of in
-    // front of them (9.7 k -> measured cycles per tile with all of a block's splits ahead of its 24 MFMAs).
+      for (int r = 0; r < 16; ++r) w[jb][r] = 0.0f;
+    auto ssp_val = [&](int ib, int r) { h[ib][r] = FAST_SSP ? ssp_fast(h[ib][r]) : ssp_exact(h[ib][r]); };
+    // The softplus in two stages of at most 24 issue cycles (what one bf16 MFMA leaves free): A = the exponential,
+    // B = logarithm and the rest.  The arithmetic is ssp_fast's.
+    // (MP_PIN: an empty volatile asm that "rewrites" the value - instruction selection lets pure arithmetic float towards
+    //  its use, across the placement fences below; a pinned result is computed where the source says.)
+#define MP_PIN(x) asm volatile("" : "+v"(x))
+    auto ssp_a = [&](int ib, int r, float& t) {
+      if constexpr (FAST_SSP) {
+        t = __builtin_amdgcn_exp2f(fabsf(h[ib][r]) * -1.4426950408889634f);
+        MP_PIN(t);
+      } else {
+        float y = ssp_exact(h[ib][r]);
+        MP_PIN(y);
+        h[ib][r] = y;
+      }
+    };
+    auto ssp_b = [&](int ib, int r, float t) {
+      if constexpr (FAST_SSP) {
+        const float l = __builtin_amdgcn_logf(__builtin_fmaf(t, 0.5f, 0.5f));
+        const int xi = __float_as_int(h[ib][r]);
+        float y = __builtin_fmaf(l, 0.6931471805599453f, __int_as_float(xi > 0 ? xi : 0));
+        MP_PIN(y);
+        h[ib][r] = y;
+      }
+    };
+    // A pieces of GEMM2's k block m: the (softplus-ed) accumulator registers 8 (m & 1) .. + 7 of hidden block m >> 1,
+    // split exactly into hi + mid + lo (bf16 each)
     auto split_into = [&](int m, int i, bf16x8& hi, bf16x8& mid, bf16x8& lo) {
       const float x = h[m >> 1][8 * (m & 1) + i];
       const __bf16 p0 = static_cast<__bf16>(x);
@@ -308,9 +318,213 @@ __global__ __launch_bounds__(WAVES * 64, (WAVES == 4 && COMPACT) ? 2 : 1) void c
       mid[i] = p1;
       lo[i] = static_cast<__bf16>(r2);
     };
+    // the same for the value pair (2 j, 2 j + 1) of k block m, in two stages: A = hi pieces and first remainders,
+    // B = mid and lo pieces
+    // the same for the value pair (2 j, 2 j + 1) of k block m - one dword of each piece vector - in two stages of packed
+    // instructions: A = v_cvt_pk_bf16_f32, widen both halves back (shift / mask), v_pk_add_f32 -> hi dword and the two
+    // first remainders; B = the same again for mid, one more conversion for lo
+    using bf16x2 = __attribute__((ext_vector_type(2))) __bf16;
+    auto pack2 = [](floatx2 v) { return __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2)); };
+    auto widen2 = [](unsigned u) { return floatx2{__uint_as_float(u << 16), __uint_as_float(u & 0xffff0000u)}; };
+    auto set_dword = [](bf16x8& v, int j, unsigned u) {
+      uint4 t = __builtin_bit_cast(uint4, v);
+      (j == 0 ? t.x : j == 1 ? t.y : j == 2 ? t.z : t.w) = u;
+      v = __builtin_bit_cast(bf16x8, t);
+    };
+    auto split2_a = [&](int m, int j, bf16x8& hi, floatx2& rem) {
+      const floatx2 x = {h[m >> 1][8 * (m & 1) + 2 * j], h[m >> 1][8 * (m & 1) + 2 * j + 1]};
+      unsigned u = pack2(x);
+      rem = x - widen2(u);           // exact
+      MP_PIN(u);
+      MP_PIN(rem);
+      set_dword(hi, j, u);
+    };
+    auto split2_b = [&](int j, bf16x8& mid, bf16x8& lo, floatx2 rem) {
+      unsigned u = pack2(rem);
+      unsigned l = pack2(rem - widen2(u));
+      MP_PIN(u);
+      MP_PIN(l);
+      set_dword(mid, j, u);
+      set_dword(lo, j, l);
+    };
+    // Placement fences: the compiler clusters MFMAs and pushes the vector work behind them (measured: 16 transcendentals
+    // after GEMM1's last MFMA, runs of 10-25 MFMAs without a vector instruction in GEMM2).  With one wave per SIMD the
+    // vector tasks are therefore pinned to their MFMA slot; with two waves per SIMD (WAVES = 8) the sibling wave's MFMAs
+    // fill this wave's vector phases and only whole steps are pinned.
+#define MP_SLOT_FENCE() do { if constexpr (G1B && WAVES == 4) __builtin_amdgcn_sched_barrier(0); } while (0)
+#define MP_STEP_FENCE() do { if constexpr (G1B) __builtin_amdgcn_sched_barrier(0); } while (0)
     bf16x8 a_hi, a_mid, a_lo;
+    if constexpr (G1B) {
+      // On the bf16 pipe, FP32-exact like GEMM2: the lane's basis values (B operand; slot s = 8 kb + i of its half) are
+      // split into three bf16 pieces in registers, W1's pieces come pre-split from LDS (A operand: row = hidden feature
+      // 32 ib + c), six products per (hidden block, k block), smallest first: 48 MFMAs of 32 cycles replace 44 FP32
+      // MFMAs of 64 that also block the vector lanes.  A bf16 MFMA holds the vector issue for 8 of its 32 cycles; the
+      // vector work that follows GEMM1 is placed in those shadows: GEMM2's accumulator initialisation (b2) under hidden
+      // block 0, the shifted softplus of hidden block 0 and the split of GEMM2's first k block under hidden blocks
+      // 1..3, and the softplus of k block m + 2 next to the split of k block m + 1 under GEMM2's k block m.
+      const unsigned w1b_addr = static_cast<unsigned>(reinterpret_cast<size_t>(
+          (__attribute__((address_space(3))) const char*)(reinterpret_cast<const char*>(W1s) + lane * 16)));
+#define MP_G1_READ6(dst, ibn)                                                                                              \
+    asm volatile("ds_read_b128 %0, %6 offset:%7\n\tds_read_b128 %1, %6 offset:%8\n\tds_read_b128 %2, %6 offset:%9\n\t"     \
+                 "ds_read_b128 %3, %6 offset:%10\n\tds_read_b128 %4, %6 offset:%11\n\tds_read_b128 %5, %6 offset:%12"       \
+                 : "=&v"(dst[0][0]), "=&v"(dst[0][1]), "=&v"(dst[0][2]), "=&v"(dst[1][0]), "=&v"(dst[1][1]),               \
+                   "=&v"(dst[1][2])                                                                                         \
+                 : "v"(w1b_addr), "n"(((0 * 2 + 0) * 4 + (ibn)) * 1024), "n"(((1 * 2 + 0) * 4 + (ibn)) * 1024),            \
+                   "n"(((2 * 2 + 0) * 4 + (ibn)) * 1024), "n"(((0 * 2 + 1) * 4 + (ibn)) * 1024),                           \
+                   "n"(((1 * 2 + 1) * 4 + (ibn)) * 1024), "n"(((2 * 2 + 1) * 4 + (ibn)) * 1024))
+#define MP_G1_WAIT6(dst)                                                                                                   \
+    asm volatile("s_waitcnt lgkmcnt(0)"                                                                                    \
+                 : "+v"(dst[0][0]), "+v"(dst[0][1]), "+v"(dst[0][2]), "+v"(dst[1][0]), "+v"(dst[1][1]), "+v"(dst[1][2]))
+      bf16x8 ga[2][3];   // (one wave per SIMD) A pieces of the current hidden block: block 0's fly under the basis split
+      if constexpr (WAVES == 4) {
+        MP_G1_READ6(ga, 0);
+        MP_SLOT_FENCE();
+      }
+      bf16x8 q[2][3];
 #pragma unroll
-    for (int i = 0; i < 8; ++i) split_into(0, i, a_hi, a_mid, a_lo);
+      for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+          const int sl = 8 * kb + i;
+          const float x = sl < NKMAX ? rb[sl < NKMAX ? sl : 0] : 0.0f;
+          const __bf16 p0 = static_cast<__bf16>(x);
+          const float r1 = x - static_cast<float>(p0);
+          const __bf16 p1 = static_cast<__bf16>(r1);
+          const float r2 = r1 - static_cast<float>(p1);
+          q[kb][0][i] = p0;
+          q[kb][1][i] = p1;
+          q[kb][2][i] = static_cast<__bf16>(r2);
+        }
+      // vector task t of hidden blocks 1..3 (36 MFMA slots, 40 tasks): 0..31 = softplus stage (t & 1) of h[0][t >> 1],
+      // 32..39 = split stage (t & 1) of value pair (t - 32) >> 1 of k block 0
+      float g1_t = 0.0f;
+      floatx2 g1_rem = {0.0f, 0.0f};
+      auto g1_task = [&](int t) {
+        if (t < 32) {
+          if (t & 1) ssp_b(0, t >> 1, g1_t);
+          else ssp_a(0, t >> 1, g1_t);
+        } else if (t & 1) {
+          split2_b((t - 32) >> 1, a_mid, a_lo, g1_rem);
+        } else {
+          split2_a(0, (t - 32) >> 1, a_hi, g1_rem);
+        }
+      };
+      auto g1_slot_tasks = [&](int ib, int sl) {   // sl = 6 kb + product within the hidden block
+        if (ib > 0) {
+          const int g = 12 * (ib - 1) + sl;
+          for (int t = (40 * g) / 36; t < (40 * (g + 1)) / 36; ++t) g1_task(t);
+        }
+      };
+      constexpr int PA[6] = {2, 0, 1, 1, 0, 0}, PB[6] = {0, 2, 1, 0, 1, 0};   // (A piece, B piece), smallest product first
+      if constexpr (WAVES > 4) {
+        const char* w1b_lane = reinterpret_cast<const char*>(W1s) + lane * 16;  // + ((piece * 2 + kb) * 4 + ib) * 1024
+#pragma unroll
+        for (int ib = 0; ib < 4; ++ib) {
+#pragma unroll
+          for (int kb = 0; kb < 2; ++kb) {
+            bf16x8 ga[3];
+#pragma unroll
+            for (int pc = 0; pc < 3; ++pc)
+              ga[pc] = *reinterpret_cast<const bf16x8*>(w1b_lane + ((pc * 2 + kb) * 4 + ib) * 1024);
+#pragma unroll
+            for (int pr = 0; pr < 6; ++pr) {
+              h[ib] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ga[PA[pr]], q[kb][PB[pr]], h[ib], 0, 0, 0);
+              g1_slot_tasks(ib, 6 * kb + pr);
+            }
+          }
+          MP_STEP_FENCE();
+        }
+      } else {
+        // one wave per SIMD: the six A pieces of hidden block ib + 1 are requested (volatile asm, program order) ahead
+        // of block ib's MFMAs; the wait that publishes them closes the block (cf. GEMM2 below)
+        if constexpr (WAVES == 4) {   // the basis pieces exist before the wait (and so before the first MFMA)
+#pragma unroll
+          for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+            for (int pc = 0; pc < 3; ++pc) asm volatile("" : "+v"(q[kb][pc]));
+        }
+        MP_SLOT_FENCE();
+        MP_G1_WAIT6(ga);
+        MP_SLOT_FENCE();
+#pragma unroll
+        for (int ib = 0; ib < 4; ++ib) {
+          bf16x8 gn[2][3];
+          if (ib < 3) {
+            MP_G1_READ6(gn, ib + 1);
+            MP_SLOT_FENCE();
+          }
+#pragma unroll
+          for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+            for (int pr = 0; pr < 6; ++pr) {
+              h[ib] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ga[kb][PA[pr]], q[kb][PB[pr]], h[ib], 0, 0, 0);
+              g1_slot_tasks(ib, 6 * kb + pr);
+              MP_SLOT_FENCE();
+            }
+          if (ib < 3) {
+            MP_G1_WAIT6(gn);
+            MP_SLOT_FENCE();
+#pragma unroll
+            for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+              for (int pc = 0; pc < 3; ++pc) ga[kb][pc] = gn[kb][pc];
+          }
+        }
+#undef MP_G1_READ6
+#undef MP_G1_WAIT6
+      }
+      MP_STAMP(2)
+    } else {
+#pragma unroll
+      for (int s = 0; s < NKMAX; ++s) {
+        if (s < nk) {
+          const float4 wv = *reinterpret_cast<const float4*>(w1_lane + s * F);
+          h[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(wv.x, rb[s], h[0], 0, 0, 0);
+          h[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(wv.y, rb[s], h[1], 0, 0, 0);
+          h[2] = __builtin_amdgcn_mfma_f32_32x32x2f32(wv.z, rb[s], h[2], 0, 0, 0);
+          h[3] = __builtin_amdgcn_mfma_f32_32x32x2f32(wv.w, rb[s], h[3], 0, 0, 0);
+        }
+      }
+      MP_STAMP(2)
+#pragma unroll
+      for (int ib = 0; ib < 4; ++ib)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) ssp_val(ib, r);
+#pragma unroll
+      for (int i = 0; i < 8; ++i) split_into(0, i, a_hi, a_mid, a_lo);
+    }
+
+    if constexpr (X_AT == 1) load_sender_rows();
+    MP_STAMP(3)
+    // ---- GEMM2: w[e][j] = sum_f h[e][f] W2[f][j] + b2[j]; A = the accumulator registers of GEMM1, split into three
+    //      bf16 pieces per k block (16 features: 8 registers of each lane half); B = the pre-split images in LDS, one
+    //      ds_read_b128 per piece; six v_mfma_f32_32x32x16_bf16 per (k block, column block), smallest products first.
+    //      Vector tasks of step (k block m, column block jb), one per MFMA slot: the split of value pair jb of k block
+    //      m + 1 (stages A, B) and - bf16 GEMM1 builds - the softplus of the same pair of k block m + 2 (stages A, B
+    //      of each value): every value is ready one k block before its split. ----
+    float st_t0 = 0.0f, st_t1 = 0.0f;
+    floatx2 st_rem = {0.0f, 0.0f};
+    auto step_task = [&](int m, int jb, int pr, bf16x8& n_hi, bf16x8& n_mid, bf16x8& n_lo) {
+      if constexpr (G1B) {
+        const int mm = m + 2, ib2 = (mm >> 1) & 3, r0 = 8 * (mm & 1) + 2 * jb;
+        if (pr == 0 && m < 7) split2_a(m + 1, jb, n_hi, st_rem);
+        if (pr == 1 && m < 6) ssp_a(ib2, r0, st_t0);
+        if (pr == 2 && m < 6) ssp_b(ib2, r0, st_t0);
+        if (pr == 3 && m < 7) split2_b(jb, n_mid, n_lo, st_rem);
+        if (pr == 4 && m < 6) ssp_a(ib2, r0 + 1, st_t1);
+        if (pr == 5 && m < 6) ssp_b(ib2, r0 + 1, st_t1);
+      } else {
+        if (pr == 5 && m < 7) {
+          split_into(m + 1, 2 * jb, n_hi, n_mid, n_lo);
+          split_into(m + 1, 2 * jb + 1, n_hi, n_mid, n_lo);
+        }
+      }
+    };
+    // one MFMA slot: product (A piece, B piece) - smallest products first - then the slot's vector task
+#define MP_G2_SLOT(pr, AP, BP)                                               \
+    w[jb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(AP, BP, w[jb], 0, 0, 0); \
+    step_task(m, jb, pr, n_hi, n_mid, n_lo);                                 \
+    MP_SLOT_FENCE()
     if constexpr (WAVES > 4) {
       // two waves per SIMD: the sibling wave's MFMAs cover this wave's LDS latency, and the 256-register budget has no
       // room for a second set of B pieces - plain reads, scheduled by the compiler
@@ -319,19 +533,17 @@ __global__ __launch_bounds__(WAVES * 64, (WAVES == 4 && COMPACT) ? 2 : 1) void c
         bf16x8 n_hi, n_mid, n_lo;
 #pragma unroll
         for (int jb = 0; jb < 4; ++jb) {
-          const bf16x8 b_hi = *reinterpret_cast<const bf16x8*>(w2_lane + (0 * 32 + 4 * m + jb) * 1024);
-          const bf16x8 b_mid = *reinterpret_cast<const bf16x8*>(w2_lane + (1 * 32 + 4 * m + jb) * 1024);
-          const bf16x8 b_lo = *reinterpret_cast<const bf16x8*>(w2_lane + (2 * 32 + 4 * m + jb) * 1024);
-          w[jb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_lo, b_hi, w[jb], 0, 0, 0);
-          w[jb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_hi, b_lo, w[jb], 0, 0, 0);
-          w[jb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_mid, b_mid, w[jb], 0, 0, 0);
-          w[jb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_mid, b_hi, w[jb], 0, 0, 0);
-          w[jb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_hi, b_mid, w[jb], 0, 0, 0);
-          w[jb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_hi, b_hi, w[jb], 0, 0, 0);
-          if (m < 7) {
-            split_into(m + 1, 2 * jb, n_hi, n_mid, n_lo);
-            split_into(m + 1, 2 * jb + 1, n_hi, n_mid, n_lo);
-          }
+          bf16x8 bq[3];
+#pragma unroll
+          for (int pc = 0; pc < 3; ++pc)
+            bq[pc] = *reinterpret_cast<const bf16x8*>(w2_lane + (pc * 32 + 4 * m + jb) * 1024);
+          MP_G2_SLOT(0, a_lo, bq[0]);
+          MP_G2_SLOT(1, a_hi, bq[2]);
+          MP_G2_SLOT(2, a_mid, bq[1]);
+          MP_G2_SLOT(3, a_mid, bq[0]);
+          MP_G2_SLOT(4, a_hi, bq[1]);
+          MP_G2_SLOT(5, a_hi, bq[0]);
+          MP_STEP_FENCE();
         }
         a_hi = n_hi;
         a_mid = n_mid;
@@ -347,43 +559,46 @@ __global__ __launch_bounds__(WAVES * 64, (WAVES == 4 && COMPACT) ? 2 : 1) void c
       const unsigned w2_addr_mid = w2_addr + 32 * 1024, w2_addr_lo = w2_addr + 64 * 1024;
 #define MP_LDS_B128(dst, addr, t) \
     asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"((t) * 1024))
-      bf16x8 b_hi, b_mid, b_lo;
-      MP_LDS_B128(b_hi, w2_addr, 0);
-      MP_LDS_B128(b_mid, w2_addr_mid, 0);
-      MP_LDS_B128(b_lo, w2_addr_lo, 0);
-      asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(b_hi), "+v"(b_mid), "+v"(b_lo));
+      bf16x8 bq[3];
+      MP_LDS_B128(bq[0], w2_addr, 0);
+      MP_LDS_B128(bq[1], w2_addr_mid, 0);
+      MP_LDS_B128(bq[2], w2_addr_lo, 0);
+      asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(bq[0]), "+v"(bq[1]), "+v"(bq[2]));
+      MP_SLOT_FENCE();
 #pragma unroll
       for (int m = 0; m < 8; ++m) {
         bf16x8 n_hi, n_mid, n_lo;
 #pragma unroll
         for (int jb = 0; jb < 4; ++jb) {
-          bf16x8 c_hi, c_mid, c_lo;
+          bf16x8 cq[3];
           if (4 * m + jb + 1 < 32) {
             // (the accumulator operand orders the reads AHEAD of this step's MFMAs; nothing touches it)
-#define MP_READ_NEXT_B(ACC)                                                                                                \
-    asm volatile("ds_read_b128 %0, %3 offset:%6\n\tds_read_b128 %1, %4 offset:%6\n\tds_read_b128 %2, %5 offset:%6"            \
-                 : "=&v"(c_hi), "=&v"(c_mid), "=&v"(c_lo)                                                                    \
-                 : "v"(w2_addr), "v"(w2_addr_mid), "v"(w2_addr_lo), "n"((4 * m + jb + 1) * 1024), ACC(w[jb]));             \
-    asm volatile("" : "+" ACC(w[jb]));
-            MP_READ_NEXT_B("a")
-#undef MP_READ_NEXT_B
+            if constexpr (G1B) {   // (the slot fences keep the reads ahead of the MFMAs)
+              asm volatile("ds_read_b128 %0, %3 offset:%6\n\tds_read_b128 %1, %4 offset:%6\n\tds_read_b128 %2, %5 offset:%6"
+                           : "=&v"(cq[0]), "=&v"(cq[1]), "=&v"(cq[2])
+                           : "v"(w2_addr), "v"(w2_addr_mid), "v"(w2_addr_lo), "n"((4 * m + jb + 1) * 1024));
+              MP_SLOT_FENCE();
+            } else {
+              asm volatile("ds_read_b128 %0, %3 offset:%6\n\tds_read_b128 %1, %4 offset:%6\n\tds_read_b128 %2, %5 offset:%6"
+                           : "=&v"(cq[0]), "=&v"(cq[1]), "=&v"(cq[2])
+                           : "v"(w2_addr), "v"(w2_addr_mid), "v"(w2_addr_lo), "n"((4 * m + jb + 1) * 1024), "a"(w[jb]));
+              asm volatile("" : "+a"(w[jb]));
+            }
           }
-          w[jb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_lo, b_hi, w[jb], 0, 0, 0);
-          w[jb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_hi, b_lo, w[jb], 0, 0, 0);
-          w[jb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_mid, b_mid, w[jb], 0, 0, 0);
-          w[jb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_mid, b_hi, w[jb], 0, 0, 0);
-          w[jb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_hi, b_mid, w[jb], 0, 0, 0);
-          w[jb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_hi, b_hi, w[jb], 0, 0, 0);
-          if (m < 7) {
-            split_into(m + 1, 2 * jb, n_hi, n_mid, n_lo);
-            split_into(m + 1, 2 * jb + 1, n_hi, n_mid, n_lo);
-          }
+          MP_G2_SLOT(0, a_lo, bq[0]);
+          MP_G2_SLOT(1, a_hi, bq[2]);
+          MP_G2_SLOT(2, a_mid, bq[1]);
+          MP_G2_SLOT(3, a_mid, bq[0]);
+          MP_G2_SLOT(4, a_hi, bq[1]);
+          MP_G2_SLOT(5, a_hi, bq[0]);
           if (4 * m + jb + 1 < 32) {
             // the accumulator operand only orders this wait behind the step's MFMAs (nothing reads it)
-            asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(c_hi), "+v"(c_mid), "+v"(c_lo), "+a"(w[jb]));
-            b_hi = c_hi;
-            b_mid = c_mid;
-            b_lo = c_lo;
+            if constexpr (G1B) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(cq[0]), "+v"(cq[1]), "+v"(cq[2]));
+            else asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(cq[0]), "+v"(cq[1]), "+v"(cq[2]), "+a"(w[jb]));
+            bq[0] = cq[0];
+            bq[1] = cq[1];
+            bq[2] = cq[2];
+            MP_SLOT_FENCE();
           }
         }
         a_hi = n_hi;
@@ -392,6 +607,10 @@ __global__ __launch_bounds__(WAVES * 64, (WAVES == 4 && COMPACT) ? 2 : 1) void c
       }
 #undef MP_LDS_B128
     }
+#undef MP_G2_SLOT
+#undef MP_PIN
+#undef MP_SLOT_FENCE
+#undef MP_STEP_FENCE
 
     MP_STAMP(4)
     if constexpr (X_AT == 2) load_sender_rows();
@@ -417,15 +636,16 @@ __global__ __launch_bounds__(WAVES * 64, (WAVES == 4 && COMPACT) ? 2 : 1) void c
         for (int jb = 0; jb < 4; ++jb) xv[jb][r] = r < rows_valid ? xv[jb][r] : 0.0f;
     }
     // features (4c, 4c+1) and (4c+2, 4c+3) as register pairs: v_pk_mul_f32 / v_pk_add_f32 do two columns per instruction
-    floatx2 acc01 = floatx2{w[0][0], w[1][0]} * floatx2{xv[0][0], xv[1][0]};
-    floatx2 acc23 = floatx2{w[2][0], w[3][0]} * floatx2{xv[2][0], xv[3][0]};
+    const floatx2 b01 = {bias2[0], bias2[1]}, b23 = {bias2[2], bias2[3]};   // filter = h W2 + b2, as Dense adds it
+    floatx2 acc01 = (floatx2{w[0][0], w[1][0]} + b01) * floatx2{xv[0][0], xv[1][0]};
+    floatx2 acc23 = (floatx2{w[2][0], w[3][0]} + b23) * floatx2{xv[2][0], xv[3][0]};
     floatx2 first01 = {0.0f, 0.0f}, first23 = {0.0f, 0.0f};
     unsigned had = 0;  // scalar: bit 0 / 1 = a segment has opened inside the low / high half
 #pragma unroll
     for (int r = 1; r < 16; ++r) {
       const unsigned o = (sm >> r) & 0x10001u;  // bit 0: edge r opens a segment; bit 16: edge 16 + r does
-      const floatx2 m01 = floatx2{w[0][r], w[1][r]} * floatx2{xv[0][r], xv[1][r]};
-      const floatx2 m23 = floatx2{w[2][r], w[3][r]} * floatx2{xv[2][r], xv[3][r]};
+      const floatx2 m01 = (floatx2{w[0][r], w[1][r]} + b01) * floatx2{xv[0][r], xv[1][r]};
+      const floatx2 m23 = (floatx2{w[2][r], w[3][r]} + b23) * floatx2{xv[2][r], xv[3][r]};
       if (o != 0) {
         const bool o_lo = (o & 1u) != 0, o_hi = (o >> 16) != 0;
         const unsigned long long open_mask = (o_lo ? LO : 0ull) | (o_hi ? HI : 0ull);
@@ -504,8 +724,10 @@ __global__ __launch_bounds__(WAVES * 64, (WAVES == 4 && COMPACT) ? 2 : 1) void c
     }
     MP_STAMP(7)
   }
-  if (!w1_ready) __syncthreads();  // a wave without tiles still owes the workgroup its two barriers
-  if (!w2_ready) __syncthreads();
+  if (!w_ready) {  // a wave without tiles still owes the workgroup its barrier (and must not exit under its own DMA)
+    __builtin_amdgcn_s_waitcnt(0x0F70);
+    __syncthreads();
+  }
   if constexpr (DIAG) {
     if (lane == 0 && a.diag) {
 #pragma unroll
@@ -514,7 +736,7 @@ __global__ __launch_bounds__(WAVES * 64, (WAVES == 4 && COMPACT) ? 2 : 1) void c
   }
 }
 
-constexpr int PACKED_FLOATS = MAX_KROWS * F + W2_IMG_FLOATS + F;
+constexpr int PACKED_FLOATS = MAX_KROWS * F + W2_IMG_FLOATS + F + W1B_FLOATS;
 
 // LDS image of the filter-MLP weights: row k of W1 (k < B), the bias b1 as row B, zero rows up to MAX_KROWS, each row
 // stored [4*c + blk] = W1[k][blk*32 + c]; then the three bf16 operand images of W2 (see W2_PIECE_FLOATS; lane c of GEMM2
@@ -549,8 +771,33 @@ __global__ void cfconv_pack_kernel(const float* __restrict__ W1, const float* __
         bits[e] = static_cast<unsigned>(__builtin_bit_cast(unsigned short, pick));
       }
       v = __uint_as_float(bits[0] | (bits[1] << 16));
-    } else {
+    } else if (i < MAX_KROWS * F + W2_IMG_FLOATS + F) {
       v = b2 ? b2[i - MAX_KROWS * F - W2_IMG_FLOATS] : 0.0f;
+    } else {
+      // bf16 pieces of W1 | b1 for GEMM1 on the bf16 pipe (see W1B_FLOATS); zeros when the basis needs a third k block
+      const int t = i - (MAX_KROWS * F + W2_IMG_FLOATS + F);
+      const int q = t & 3, ln = (t >> 2) & 63, e = t >> 8;
+      const int ib = e & 3, kb = (e >> 2) & 1, piece = e >> 3;
+      const int cc = ln & 31, hh = ln >> 5;
+      const int nk = (B + 2) >> 1;
+      unsigned bits[2] = {0u, 0u};
+      if (nk <= G1B_MAX_NK) {
+        for (int e2 = 0; e2 < 2; ++e2) {
+          const int sl = 8 * kb + 2 * q + e2;
+          const int k = sl < nk ? sl + nk * hh : MAX_KROWS;
+          float x = 0.0f;
+          if (k < B) x = W1[k * F + 32 * ib + cc];
+          else if (k == B && b1) x = b1[32 * ib + cc];
+          const __bf16 p0 = static_cast<__bf16>(x);
+          const float r1 = x - static_cast<float>(p0);
+          const __bf16 p1 = static_cast<__bf16>(r1);
+          const float r2 = r1 - static_cast<float>(p1);
+          const __bf16 p2 = static_cast<__bf16>(r2);
+          const __bf16 pick = piece == 0 ? p0 : (piece == 1 ? p1 : p2);
+          bits[e2] = static_cast<unsigned>(__builtin_bit_cast(unsigned short, pick));
+        }
+      }
+      v = __uint_as_float(bits[0] | (bits[1] << 16));
     }
     packed[i] = v;
   }
@@ -601,7 +848,8 @@ inline int ensure_dynamic_lds(const void* kernel, size_t lds, unsigned long long
 
 template <int WAVES, int NKT>
 size_t cfconv_lds_bytes() {
-  return sizeof(float) * ((NKT > 0 ? 2 * NKT : MAX_KROWS) * F + W2_IMG_FLOATS + WAVES * 2 * F);
+  const int w1 = (NKT > 0 && NKT <= G1B_MAX_NK) ? W1B_FLOATS : (NKT > 0 ? 2 * NKT : MAX_KROWS) * F;
+  return sizeof(float) * (w1 + W2_IMG_FLOATS + WAVES * 2 * F);
 }
 
 template <int WAVES, bool GAUSS, bool FAST, int NKT, bool DIAG, bool COMPACT = false>
