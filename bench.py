@@ -252,9 +252,10 @@ def run_config2(args, d):
         "metric": "edges/sec (SchNet fwd, QM9-shape batch)", "value": total_edges * args.steps / elapsed,
         "unit": "edges/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-        "precision": "float32 inputs, weights and results; the K=128 filter GEMM of the cfconv kernel is evaluated on the bf16 "
-                     "matrix pipe as an exact FP32 emulation (3 bf16 pieces per operand, 6 products, FP32 accumulate; error "
-                     "equal to the FP32 MFMA chain's: scripts/probes/bf16x3_probe.hip, tests/test_gpu_fused.py)",
+        "precision": "float32 inputs, weights and results; both filter GEMMs of the cfconv kernel (K=21 and K=128) are "
+                     "evaluated on the bf16 matrix pipe as an exact FP32 emulation (3 bf16 pieces per operand, 6 products, "
+                     "FP32 accumulate; error equal to the FP32 MFMA chain's: scripts/probes/bf16x3_probe.hip, "
+                     "tests/test_gpu_fused.py)",
         "config": {"workload": "BASELINE config 2: Schnet.make_model forward (F=128, depth 3, Gauss 20) on %d QM9-shaped "
                                "graphs per GPU, N=%d nodes, M=%d directed edges on rank 0"
                                % (n_graphs, n_nodes, n_edges),

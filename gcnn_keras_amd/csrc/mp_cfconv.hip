@@ -47,6 +47,7 @@
 //  * The output buffer must be zero on entry (unconnected nodes keep 0 = the has_unconnected pad of
 //    kgcnn/layers/pooling.py:74-76).
 #include <mutex>
+#include <type_traits>
 
 #include "mp_common.h"
 
@@ -127,6 +128,9 @@ __global__ __launch_bounds__(WAVES * 64, (WAVES == 4 && COMPACT) ? 2 : 1) void c
   // rows of W1 kept in LDS: all MAX_KROWS in the generic build, the 2 nk that GEMM1 reads when the basis size is fixed
   // (22 for B = 20: the workgroup then needs 79.3 KB, so two workgroups - e.g. of two forwards in flight - share a CU)
   constexpr bool G1B = NKT > 0 && NKT <= G1B_MAX_NK;   // GEMM1 on the bf16 pipe (three pieces per operand, like GEMM2)
+  // hand-placed pipeline (volatile-asm LDS reads one step ahead, vector tasks pinned to MFMA slots): one wave per SIMD.
+  // (With two waves per SIMD the same placement measured equal to the compiler's within noise: 496 vs 503 us at 2.5 M edges.)
+  constexpr bool PIPE = G1B && WAVES == 4;
   constexpr int W1ROWS = NKT > 0 ? 2 * NKT : MAX_KROWS;
   constexpr int W1_LDS_FLOATS = G1B ? W1B_FLOATS : W1ROWS * F;
   float* W1s = lds;                          // [W1ROWS][F] packed, or the bf16 piece image (W1B_FLOATS)
@@ -171,33 +175,61 @@ __global__ __launch_bounds__(WAVES * 64, (WAVES == 4 && COMPACT) ? 2 : 1) void c
   prefetch_tile(tile_first);
 
   // ---- stage the pre-packed weights once per workgroup, all of them by LDS-DMA (global_load_lds_dwordx4: 1 KB per wave
-  //      instruction, no VGPRs, nothing to wait for here): the W1 image first, then the three W2 images.  (Round 1 sent
-  //      W1 through registers in a rolled load -> wait -> ds_write loop: three serial round trips to L2 before the first
-  //      tile could start.)  The one barrier that publishes the weights sits right before the first GEMM1. ----------------
+  //      instruction, no VGPRs, nothing to wait for at the point of issue): W1's image, then the three W2 images.  (Round 1
+  //      sent W1 through registers in a rolled load -> wait -> ds_write loop: three serial round trips to L2 before the
+  //      first tile could start.)  The 120 KB take ~2 k cycles to arrive (64 B per clock and CU) - about the round trip of
+  //      the first tile's edge data, which was requested just before them and whose wait (vmcnt retires in order) is also
+  //      theirs.  One barrier, right before the first GEMM1, publishes the weights; it does not wait for the sender rows.
+  //      (Measured and not kept: W2 requested after the edge data's wait so that it flies under GEMM1 - the requests then
+  //      start a round trip later and GEMM2 waits for them: 10.9 vs 10.7 us at config 2.) ---------------------------------
   float bias2[4];
 #pragma unroll
   for (int jb = 0; jb < 4; ++jb) bias2[jb] = a.packed[MAX_KROWS * F + W2_IMG_FLOATS + 4 * c + jb];
-  {
+  constexpr int W2_CHUNKS_PER_WAVE = (W2_IMG_FLOATS / 256) / WAVES;  // 1-KB chunks of the W2 images per wave: 24 or 12
+  auto request_weights = [&]() {
     constexpr int W1_CHUNKS = W1_LDS_FLOATS / 256;
     static_assert(W1_LDS_FLOATS % 256 == 0, "the W1 image is staged in 1-KB chunks");
     const float* src1 = a.packed + (G1B ? MAX_KROWS * F + W2_IMG_FLOATS + F : 0);
 #pragma unroll
     for (int i = 0; i < (W1_CHUNKS + WAVES - 1) / WAVES; ++i) {
-      const int chunk = i * WAVES + wave;
+      const int chunk = i * WAVES + wave;   // (few chunks, needed first: not rotated)
       if (chunk < W1_CHUNKS)
         __builtin_amdgcn_global_load_lds(src1 + chunk * 256 + lane * 4,
                                          (__attribute__((address_space(3))) void*)(W1s + chunk * 256), 16, 0, 0);
     }
-    constexpr int CHUNKS_PER_WAVE = (W2_IMG_FLOATS / 256) / WAVES;  // 1-KB chunks of the W2 images per wave
     const float* src = a.packed + MAX_KROWS * F;
 #pragma unroll
-    for (int i = 0; i < CHUNKS_PER_WAVE; ++i) {
-      const int chunk = wave * CHUNKS_PER_WAVE + i;
+    for (int i = 0; i < W2_CHUNKS_PER_WAVE; ++i) {
+      const int chunk = wave * W2_CHUNKS_PER_WAVE + i;
       __builtin_amdgcn_global_load_lds(src + chunk * 256 + lane * 4,
                                        (__attribute__((address_space(3))) void*)(W2s + chunk * 256), 16, 0, 0);
     }
-  }
-  bool w_ready = false;  // wave-uniform: every wave passes the publishing barrier exactly once
+  };
+  // s_waitcnt vmcnt(N), N < 64: everything but the wave's N youngest vector-memory operations has completed (they retire
+  // in order).  bf16-GEMM1 build with one wave per SIMD: every LDS read of the weights is volatile asm, so a bare
+  // s_barrier behind an explicit, exact wait orders them; the other builds read weights in plain C++ and take a full
+  // drain and the fenced __syncthreads().
+  auto publish = [&](auto vm_outstanding) {
+    constexpr int N = decltype(vm_outstanding)::value;
+    if constexpr (WAVES == 4 && G1B) {
+      __builtin_amdgcn_s_waitcnt(0x0F70 | (N & 15) | ((N >> 4) << 14));
+      __builtin_amdgcn_s_barrier();
+    } else {
+      __builtin_amdgcn_s_waitcnt(0x0F70);
+      __syncthreads();
+    }
+  };
+  // A wave WITH a tile has, at the barrier, issued behind the weight requests: the loads of its edge data (waited for
+  // at tile start - which drains the requests, too), then (sender rows at tile start) 16 row loads and 0-4 loads of the
+  // next tile's edge data.  "All but the youngest 16" therefore covers the weights and leaves the rows in flight.
+  constexpr int ROWS_EARLY = (WAVES == 4 && !COMPACT) ? 16 : 0;
+  using AllButRows = std::integral_constant<int, ROWS_EARLY>;
+  using Everything = std::integral_constant<int, 0>;
+  request_weights();
+  // (Measured and not kept, config 2, against 10.5 us: the first tile's edge data by volatile-asm loads awaited by hand
+  //  with the exact count, so that the tile starts under the weight transfer - 10.7 us, the barrier then waits for the
+  //  same transfer; a per-workgroup rotation of the chunk order against L2 channel queueing - 11.0 us.)
+  bool w_ready = false;   // wave-uniform: every wave passes the publishing barrier exactly once
 
   MP_STAMP(0)
   const float* w1_lane = W1s + (nk * hh) * F + 4 * c;  // + s*F           : rows s (lo half) / nk+s (hi half)
@@ -265,8 +297,7 @@ __global__ __launch_bounds__(WAVES * 64, (WAVES == 4 && COMPACT) ? 2 : 1) void c
     }
 
     if (!w_ready) {
-      __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0): this wave's share of the weight DMA has landed
-      __syncthreads();                     // ... and so has every other wave's
+      publish(AllButRows{});  // this wave's share of the weights has landed, and after the barrier every other wave's
       w_ready = true;
     }
     MP_STAMP(1)
@@ -351,7 +382,7 @@ __global__ __launch_bounds__(WAVES * 64, (WAVES == 4 && COMPACT) ? 2 : 1) void c
     // after GEMM1's last MFMA, runs of 10-25 MFMAs without a vector instruction in GEMM2).  With one wave per SIMD the
     // vector tasks are therefore pinned to their MFMA slot; with two waves per SIMD (WAVES = 8) the sibling wave's MFMAs
     // fill this wave's vector phases and only whole steps are pinned.
-#define MP_SLOT_FENCE() do { if constexpr (G1B && WAVES == 4) __builtin_amdgcn_sched_barrier(0); } while (0)
+#define MP_SLOT_FENCE() do { if constexpr (PIPE) __builtin_amdgcn_sched_barrier(0); } while (0)
 #define MP_STEP_FENCE() do { if constexpr (G1B) __builtin_amdgcn_sched_barrier(0); } while (0)
     bf16x8 a_hi, a_mid, a_lo;
     if constexpr (G1B) {
@@ -376,7 +407,7 @@ __global__ __launch_bounds__(WAVES * 64, (WAVES == 4 && COMPACT) ? 2 : 1) void c
     asm volatile("s_waitcnt lgkmcnt(0)"                                                                                    \
                  : "+v"(dst[0][0]), "+v"(dst[0][1]), "+v"(dst[0][2]), "+v"(dst[1][0]), "+v"(dst[1][1]), "+v"(dst[1][2]))
       bf16x8 ga[2][3];   // (one wave per SIMD) A pieces of the current hidden block: block 0's fly under the basis split
-      if constexpr (WAVES == 4) {
+      if constexpr (PIPE) {
         MP_G1_READ6(ga, 0);
         MP_SLOT_FENCE();
       }
@@ -416,7 +447,7 @@ __global__ __launch_bounds__(WAVES * 64, (WAVES == 4 && COMPACT) ? 2 : 1) void c
         }
       };
       constexpr int PA[6] = {2, 0, 1, 1, 0, 0}, PB[6] = {0, 2, 1, 0, 1, 0};   // (A piece, B piece), smallest product first
-      if constexpr (WAVES > 4) {
+      if constexpr (!PIPE) {
         const char* w1b_lane = reinterpret_cast<const char*>(W1s) + lane * 16;  // + ((piece * 2 + kb) * 4 + ib) * 1024
 #pragma unroll
         for (int ib = 0; ib < 4; ++ib) {
@@ -437,7 +468,7 @@ __global__ __launch_bounds__(WAVES * 64, (WAVES == 4 && COMPACT) ? 2 : 1) void c
       } else {
         // one wave per SIMD: the six A pieces of hidden block ib + 1 are requested (volatile asm, program order) ahead
         // of block ib's MFMAs; the wait that publishes them closes the block (cf. GEMM2 below)
-        if constexpr (WAVES == 4) {   // the basis pieces exist before the wait (and so before the first MFMA)
+        if constexpr (PIPE) {   // the basis pieces exist before the wait (and so before the first MFMA)
 #pragma unroll
           for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
@@ -525,7 +556,7 @@ __global__ __launch_bounds__(WAVES * 64, (WAVES == 4 && COMPACT) ? 2 : 1) void c
     w[jb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(AP, BP, w[jb], 0, 0, 0); \
     step_task(m, jb, pr, n_hi, n_mid, n_lo);                                 \
     MP_SLOT_FENCE()
-    if constexpr (WAVES > 4) {
+    if constexpr (!PIPE) {
       // two waves per SIMD: the sibling wave's MFMAs cover this wave's LDS latency, and the 256-register budget has no
       // room for a second set of B pieces - plain reads, scheduled by the compiler
 #pragma unroll
@@ -724,10 +755,8 @@ __global__ __launch_bounds__(WAVES * 64, (WAVES == 4 && COMPACT) ? 2 : 1) void c
     }
     MP_STAMP(7)
   }
-  if (!w_ready) {  // a wave without tiles still owes the workgroup its barrier (and must not exit under its own DMA)
-    __builtin_amdgcn_s_waitcnt(0x0F70);
-    __syncthreads();
-  }
+  // a wave without tiles still owes the workgroup its barrier (and must not exit under its DMA)
+  if (!w_ready) publish(Everything{});
   if constexpr (DIAG) {
     if (lane == 0 && a.diag) {
 #pragma unroll

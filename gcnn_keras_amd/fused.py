@@ -372,11 +372,13 @@ class FusedSchnet:
         # algorithmic bytes of one launch: distance + ids per edge, sender rows once, output rows once
         alg_bytes = float(self.M) * (4 + 8) + 2.0 * self.N * 128 * 4
         achieved = flops / (ms * 1e-3) / 1e12
-        # matrix-pipe occupancy of the instruction mix actually issued: per 32-edge tile GEMM1 = ceil((bins+1)/2) k steps
-        # x 4 blocks of v_mfma_f32_32x32x2_f32 (64 cycles each), GEMM2 = 8 k blocks x 4 column blocks x 6
-        # v_mfma_f32_32x32x16_bf16 (32 cycles each; FP32 emulated exactly from three bf16 pieces per operand)
+        # matrix-pipe occupancy of the instruction mix actually issued, per 32-edge tile: GEMM2 = 8 k blocks x 4 column
+        # blocks x 6 v_mfma_f32_32x32x16_bf16 (32 cycles each; FP32 emulated exactly from three bf16 pieces per operand);
+        # GEMM1 = 2 k blocks x 4 hidden blocks x 6 of the same (basis + bias row <= 32 slots: 20 bins), else
+        # ceil((bins+1)/2) k steps x 4 blocks of v_mfma_f32_32x32x2_f32 (64 cycles each)
         tiles = (self.M + 31) // 32
-        mfma_cycles = tiles * (((bins + 2) // 2) * 4 * 64 + 8 * 4 * 6 * 32)
+        gemm1_cycles = 2 * 4 * 6 * 32 if bins == 20 else ((bins + 2) // 2) * 4 * 64
+        mfma_cycles = tiles * (gemm1_cycles + 8 * 4 * 6 * 32)
         pipe_busy = mfma_cycles / (1024 * 2.4e9 * ms * 1e-3)
         return {"bound": "mfma", "kernel": "cfconv_fused_kernel<4,gauss> (SchNetCFconv, one interaction block)",
                 "achieved": achieved, "peak": mfma_peak_tf, "unit": "TFLOP/s", "frac": achieved / mfma_peak_tf,
@@ -384,7 +386,7 @@ class FusedSchnet:
                 "algorithmic_bytes_per_launch": alg_bytes,
                 "hbm_gbs_at_this_rate": alg_bytes / (ms * 1e-3) / 1e9, "hbm_peak_gbs": hbm_peak_gbs,
                 "peak_note": "peak = dense FP32 MFMA peak (MI355X_MICROARCH.md); achieved = algorithmic FP32 flops / "
-                             "time.  85 % of those flops (the K = 128 filter GEMM) are issued as six bf16 MFMAs per 16 k - "
+                             "time.  The filter GEMMs (K = 21 and K = 128) are issued as six bf16 MFMAs per 16 k - "
                              "an exact FP32 emulation from three bf16 pieces per operand, FP32 accumulate, error equal to "
                              "the FP32 MFMA chain's (scripts/probes/bf16x3_probe.hip) - so frac can exceed 1 at large "
                              "batches; matrix_pipe_busy is the share of all 1024 SIMDs' cycles (2.4 GHz) taken by the "
