@@ -896,11 +896,15 @@ int launch_cfconv(const CfconvArgs& args, int grid, hipStream_t s) {
 template <bool GAUSS, bool FAST>
 int launch_by_basis(const CfconvArgs& args, int waves, int grid, bool compact, hipStream_t s) {
   (void)compact;   // flag bit 4 selects the 8-wave build in cfconv_dispatch (two waves per SIMD on ONE LDS image)
+  // basis sizes with a compile-time k count run GEMM1 on the bf16 pipe: 20 (SchNet default) and 25 (the fork's
+  // force_schnet.py configuration); everything else takes the generic FP32 GEMM1
   if (waves == 8) {
     if (args.B == 20) return launch_cfconv<8, GAUSS, FAST, 11, false>(args, grid, s);
+    if (args.B == 25) return launch_cfconv<8, GAUSS, FAST, 13, false>(args, grid, s);
     return launch_cfconv<8, GAUSS, FAST, 0, false>(args, grid, s);
   }
-  if (args.B == 20) return launch_cfconv<4, GAUSS, FAST, 11, false>(args, grid, s);  // SchNet default: 20 bins
+  if (args.B == 20) return launch_cfconv<4, GAUSS, FAST, 11, false>(args, grid, s);
+  if (args.B == 25) return launch_cfconv<4, GAUSS, FAST, 13, false>(args, grid, s);
   return launch_cfconv<4, GAUSS, FAST, 0, false>(args, grid, s);
 }
 

@@ -65,11 +65,21 @@ __global__ __launch_bounds__(WAVES * 64, 1) void cfconv_dist_grad_kernel(CfconvB
   const int hh = lane >> 5;
   const int B = a.B;
   const int nk = (B + 2) >> 1;             // k pairs of the basis GEMMs (B inputs + bias row, padded to even)
+  // the 113 KB image by LDS-DMA (1 KB per wave instruction, no VGPRs, all requests in flight at once; the first version
+  // copied it through registers in a rolled load -> wait -> ds_write loop: 28 serial round trips to L2, a third of the
+  // kernel's time at 64 graphs)
   {
-    const float4* src = reinterpret_cast<const float4*>(a.packed);
-    float4* dst = reinterpret_cast<float4*>(lds);
-    for (int i = tid; i < PACKED_BWD_FLOATS / 4; i += WAVES * 64) dst[i] = src[i];
+    constexpr int CHUNKS = PACKED_BWD_FLOATS / 256;
+    static_assert(PACKED_BWD_FLOATS % 256 == 0, "the image is staged in 1-KB chunks");
+#pragma unroll
+    for (int i = 0; i < (CHUNKS + WAVES - 1) / WAVES; ++i) {
+      const int chunk = i * WAVES + wave;
+      if (chunk < CHUNKS)
+        __builtin_amdgcn_global_load_lds(a.packed + chunk * 256 + lane * 4,
+                                         (__attribute__((address_space(3))) void*)(lds + chunk * 256), 16, 0, 0);
+    }
   }
+  __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0): this wave's chunks have landed
   __syncthreads();
   const float* w1_lane = W1s + (nk * hh) * F + 4 * c;   // + s*F : rows s (low half) / nk + s (high half)
   const unsigned w2_addr = static_cast<unsigned>(reinterpret_cast<size_t>(
@@ -110,7 +120,7 @@ __global__ __launch_bounds__(WAVES * 64, 1) void cfconv_dist_grad_kernel(CfconvB
       const int k = s + nk * hh;
       const float mu = static_cast<float>(k) / fbins * a.g_distance;
       const float v = (d - a.g_offset) - mu;
-      const float gv = expf((v * v) * (a.g_gamma * -1.0f));
+      const float gv = __builtin_amdgcn_exp2f((v * v) * (a.g_gamma * -1.4426950408889634f));   // v_exp_f32
       const float rb = k < B ? gv : (k == B ? 1.0f : 0.0f);
       const float rbd = k < B ? gv * (-2.0f * a.g_gamma * v) : 0.0f;   // d/dd exp(-gamma v^2)
       const float4 wv = *reinterpret_cast<const float4*>(w1_lane + s * F);
@@ -127,7 +137,8 @@ __global__ __launch_bounds__(WAVES * 64, 1) void cfconv_dist_grad_kernel(CfconvB
 #pragma unroll
     for (int ib = 0; ib < 4; ++ib)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) P[ib][r] = Z[ib][r] / (1.0f + expf(-P[ib][r]));
+      for (int r = 0; r < 16; ++r)   // sigmoid on v_exp_f32 / v_rcp_f32 (1 ulp each)
+        P[ib][r] = Z[ib][r] * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(P[ib][r] * -1.4426950408889634f));
 
     // ---- GH[h][e] = sum_j W2[h][j] v[e][j] on the bf16 pipe: A = W2 pieces from LDS (read one step ahead, asm-ordered
     //      against the MFMAs as in the forward kernel), B = this lane's eight v values of the k block, split in registers ----

@@ -363,10 +363,21 @@ __global__ __launch_bounds__(256) void schnet_readout_kernel(const float* __rest
   // (use_output_mlp=False, the fork's force configuration): out[g] = sum_n (h_n . Wo1 + bo1)
   const bool linear_head = Wo0 == nullptr;
   if (!linear_head) {
-    for (int i = threadIdx.x; i < 64 * 64 / 4; i += 256)
-      reinterpret_cast<float4*>(Ws)[i] = reinterpret_cast<const float4*>(Wo0)[i];
-    if (g_pool)
-      for (int i = threadIdx.x; i < 64 * 64; i += 256) Wr[(i >> 6) * 65 + (i & 63)] = Wo0[i];
+    // four 16-B loads per thread, all requested before the first is stored (a rolled copy loop waits for every load
+    // before it issues the next: four serial round trips to L2 in a 4-us kernel)
+    float4 t[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) t[k] = reinterpret_cast<const float4*>(Wo0)[threadIdx.x + 256 * k];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) reinterpret_cast<float4*>(Ws)[threadIdx.x + 256 * k] = t[k];
+    if (g_pool) {
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const int i = 4 * (threadIdx.x + 256 * k);   // element (i >> 6, i & 63 .. + 3)
+        float* dst = Wr + (i >> 6) * 65 + (i & 63);
+        dst[0] = t[k].x; dst[1] = t[k].y; dst[2] = t[k].z; dst[3] = t[k].w;
+      }
+    }
   }
   const int lane = threadIdx.x & 63;
   const float b0v = (!linear_head && bo0) ? bo0[lane] : 0.0f;
