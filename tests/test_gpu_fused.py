@@ -15,7 +15,7 @@ def _rel_err(got, ref):
     return rowwise_rel(got, ref)
 
 
-def _cfconv_case(seed, num_graphs=9, shuffle=False):
+def _cfconv_case(seed, num_graphs=9, shuffle=False, bins=20):
     b = synth.qm9_like_batch(num_graphs=num_graphs, seed=seed)
     rng = np.random.default_rng(seed)
     idx = b["edge_indices"].copy()
@@ -29,8 +29,8 @@ def _cfconv_case(seed, num_graphs=9, shuffle=False):
     ridx = ko.R(idx, b["edge_splits"])
     p1, p2 = ko.node_position(xyz, ridx)
     dist = ko.node_distance_euclidean(p1, p2)
-    rbf = ko.gauss_basis(dist, 20, 4.0, 0.4)
-    p = {"dense1/kernel": synth.glorot_uniform(rng, 20, 128), "dense1/bias": rng.uniform(-.1, .1, 128).astype(np.float32),
+    rbf = ko.gauss_basis(dist, bins, 4.0, 0.4)
+    p = {"dense1/kernel": synth.glorot_uniform(rng, bins, 128), "dense1/bias": rng.uniform(-.1, .1, 128).astype(np.float32),
          "dense2/kernel": synth.glorot_uniform(rng, 128, 128),
          "dense2/bias": rng.uniform(-.1, .1, 128).astype(np.float32)}
     return b, x, ridx, dist, rbf, p
@@ -115,6 +115,67 @@ def test_cfconv_split_precision_gemm_keeps_the_fp32_error_budget(case, flags):
     oracle_err = _rel_err(ref, ref64)
     assert _rel_err(got, ref64) <= max(4 * oracle_err, 2e-6), (case, _rel_err(got, ref64), oracle_err)
     assert _rel_err(got, ref) <= max(1e-5, 8 * oracle_err)
+
+
+def _run_cfconv_gauss(x, ridx, dist, p, bins, flags):
+    from gcnn_keras_amd import _ffi
+    from gcnn_keras_amd.ragged import RaggedTensor
+    dx = RaggedTensor.from_numpy(x.values, x.row_splits)
+    di = RaggedTensor.from_numpy(ridx.values, ridx.row_splits)
+    plan = di.index_plan(dx)
+    _, perm, seg = plan.csr(0)
+    out = torch.zeros((plan.N, 128), dtype=torch.float32, device="cuda")
+    w = {k: torch.from_numpy(v).cuda() for k, v in p.items()}
+    packed = torch.empty(_ffi.lib().mp_cfconv_packed_floats(), dtype=torch.float32, device="cuda")
+    _ffi.call("mp_cfconv_pack_f32", _ffi.ptr(w["dense1/kernel"]), _ffi.ptr(w["dense1/bias"]), bins,
+              _ffi.ptr(w["dense2/kernel"]), _ffi.ptr(w["dense2/bias"]), _ffi.ptr(packed), _ffi.stream())
+    e = torch.from_numpy(dist.values.reshape(-1)).cuda()
+    _ffi.call("mp_cfconv_gauss_fused_f32", _ffi.ptr(dx.values), plan.N, _ffi.ptr(e), bins, 4.0, 0.4, 0.0,
+              _ffi.ptr(packed), _ffi.ptr(seg.contiguous()), _ffi.ptr(plan.col(1).contiguous()), _ffi.ptr(perm), plan.M, flags,
+              _ffi.ptr(out), _ffi.stream())
+    return out.cpu().numpy()
+
+
+@pytest.mark.parametrize("flags", [0, 1, 5])
+@pytest.mark.parametrize("bins", [20, 25, 7, 32])
+def test_cfconv_basis_sizes_vs_oracle(bins, flags):
+    """The basis sizes with their own builds - 20 (SchNet default) and 25 (the fork's force_schnet.py configuration): the
+    first filter GEMM on the bf16 pipe, W1 pre-split into three bf16 pieces - and two sizes of the generic build (odd;
+    the largest the kernel takes: FP32 matrix instructions for the first GEMM)."""
+    b, x, ridx, dist, rbf, p = _cfconv_case(27, bins=bins)
+    ref = ko.schnet_cfconv(x, rbf, ridx, p).values
+    ref64 = ko.schnet_cfconv(ko.to_dtype(x, np.float64), ko.to_dtype(rbf, np.float64), ridx,
+                             ko.to_dtype(p, np.float64)).values
+    got = _run_cfconv_gauss(x, ridx, dist, p, bins, flags)
+    assert _rel_err(got, ref) <= 1e-5
+    assert _rel_err(got, ref64) <= max(4 * _rel_err(ref, ref64), 2e-6)
+
+
+@pytest.mark.parametrize("bins", [20, 25])
+@pytest.mark.parametrize("case", ["wide_range", "large_bias", "tiny"])
+def test_cfconv_first_layer_split_precision(case, bins):
+    """GEMM1 of the 20- and 25-bin builds is an FP32 emulation on the bf16 pipe as well (W1 | b1 and the basis values in
+    three bf16 pieces, six products).  Inputs against that scheme: first-layer weights over nine orders of magnitude, a
+    bias row that dominates the sum (the bias is one of the split rows), weights near the bottom of the normal range.
+    Same bars as for GEMM2: the float32 oracle's own distance from its float64 twin."""
+    b, x, ridx, dist, rbf, p = _cfconv_case(41, bins=bins)
+    rng = np.random.default_rng(9)
+    p = {k: v.copy() for k, v in p.items()}
+    if case == "wide_range":
+        p["dense1/kernel"] *= (10.0 ** rng.uniform(-6, 2, size=p["dense1/kernel"].shape)).astype(np.float32)
+    elif case == "large_bias":
+        p["dense1/bias"] = (rng.uniform(-1, 1, 128) * 37.0).astype(np.float32)
+    else:
+        p["dense1/kernel"] *= np.float32(1e-30)
+        p["dense1/bias"] *= np.float32(1e-30)
+    ref = ko.schnet_cfconv(x, rbf, ridx, p).values
+    ref64 = ko.schnet_cfconv(ko.to_dtype(x, np.float64), ko.to_dtype(rbf, np.float64), ridx,
+                             ko.to_dtype(p, np.float64)).values
+    for flags in (0, 1):
+        got = _run_cfconv_gauss(x, ridx, dist, p, bins, flags)
+        oracle_err = _rel_err(ref, ref64)
+        assert _rel_err(got, ref64) <= max(4 * oracle_err, 2e-6), (case, flags, _rel_err(got, ref64), oracle_err)
+        assert _rel_err(got, ref) <= max(1e-5, 8 * oracle_err)
 
 
 @pytest.mark.parametrize("flags", [1, 5, 17])
