@@ -1,0 +1,21 @@
+#!/bin/bash
+# One profiling call on the GPU box: kernel traces (rocprofv3 --kernel-trace --stats) and separate --pmc passes for the
+# workloads behind profiles/r02_*.  Outputs under gpurun_out/; condense with scripts/rocprof_db_stats.py and
+# scripts/summarize_profiles.py r02.
+set -e
+cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
+B="python3 bench.py --no-cpu-baseline --no-config4-reference --steps 300"
+rocprofv3 --kernel-trace --stats -d gpurun_out/prof5_c2_1 -o b -- $B --in-flight 1 > gpurun_out/prof5_c2_1.log 2>&1
+rocprofv3 --kernel-trace --stats -d gpurun_out/prof5_c2_4 -o b -- $B > gpurun_out/prof5_c2_4.log 2>&1
+rocprofv3 --kernel-trace --stats -d gpurun_out/prof5_sf -o sf -- python3 scripts/bench_schnet_force.py 64 --profile fork 200 > gpurun_out/prof5_sf.log 2>&1
+rocprofv3 --kernel-trace --stats -d gpurun_out/prof5_pn_ef -o painn -- python3 scripts/profile_painn.py force 200 > gpurun_out/prof5_pn_ef.log 2>&1
+echo traces done
+for c in FETCH_SIZE WRITE_SIZE; do
+  n=$(echo $c | tr A-Z a-z | cut -d_ -f1)
+  rocprofv3 --pmc $c --kernel-trace --output-format csv -d gpurun_out/pmc2_$n -o p -- python3 bench.py --no-cpu-baseline --no-config4-reference --steps 200 --in-flight 1 > gpurun_out/pmc2_$n.log 2>&1
+  rocprofv3 --pmc $c --kernel-trace --output-format csv -d gpurun_out/pmc2_sf_$n -o p -- python3 scripts/bench_schnet_force.py 64 --profile fork 50 > gpurun_out/pmc2_sf_$n.log 2>&1
+  rocprofv3 --pmc $c --kernel-trace --output-format csv -d gpurun_out/pmc2_pn_$n -o p -- python3 scripts/profile_painn.py force 50 > gpurun_out/pmc2_pn_$n.log 2>&1
+  echo pmc $c done
+done
+find gpurun_out -name "*kernel_trace.csv" -size +20M -delete
+du -sh gpurun_out
