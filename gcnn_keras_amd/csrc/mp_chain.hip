@@ -13,6 +13,8 @@
 //   stage 2:  out = m W2 + b2 + addend                              (absent: out = stage 1 + addend, any U1)
 //
 // W1 / W2 are mp_chain_pack_f32 images: the k-major register order of one wave's column slice, 16-B loads.
+#include <mutex>
+
 #include "mp_common.h"
 
 namespace {
@@ -182,6 +184,174 @@ __global__ __launch_bounds__(512, 1) void dense_chain_kernel(ChainArgs a) {
   }
 }
 
+// ---------------------------------------------------------------------------------------------------- PAiNNUpdate, fused
+// PAiNNUpdate.call (kgcnn/layers/conv/painn_conv.py:201-214) around its two Dense layers, one launch per block:
+//
+//   pre    c = [z | sqrt(relu(sum_k v_v[k]^2))]  (EuclideanNorm, LazyConcatenate),  prod = sum_k v_u[k] v_v[k]  (ScalarProduct)
+//   chain  a = act(c Wd + bd) Wa + ba            (the <256, 1, 3> chain above)
+//   post   z2 = z + (prod a_sv + a_ss) ,  v2[k] = v[k] + a_vv v_u[k]      with a = [a_vv | a_sv | a_ss]   (+ PAiNN.py:131-132)
+//
+// with uv (3N, 2F) = v [Wu | Wv] from the chain launch before it.  The two element-wise kernels this replaces
+// (csrc/mp_painn_fused.hip: painn_update_pre / painn_update_post, ~5 us each at 64 graphs - launch floor - six per
+// forward) become the prologue and the epilogue of the chain: thread t of the 512 owns node t / 32 of the tile and the
+// four features 4 (t % 32) ..; what the epilogue needs again (z, prod, v_u, v) waits in LDS, the 16 x 384 output tile
+// is exchanged through LDS (a node's a_vv / a_sv / a_ss columns belong to different waves).  Same arithmetic, same
+// order as the separate kernels.  c / prod / a reach HBM only when the caller asks (the reverse pass reads them).
+struct UpdateArgs {
+  int64_t N;
+  int ntiles;
+  const float* zp;        // (N, F)
+  const float* vp;        // (N, 3, F)
+  const float* uv;        // (3N, 2F)
+  const float* W1;        // packed (256, 128)
+  const float* b1;
+  int act1;
+  float alpha1;
+  float* save_pre;        // (N, 128) or null
+  const float* W2;        // packed (128, 384)
+  const float* b2;
+  float* c_out;           // (N, 2F) or null
+  float* prod_out;        // (N, F) or null
+  float* a_out;           // (N, 3F) or null
+  float* z2;              // (N, F)
+  float* v2;              // (N, 3, F)
+};
+
+constexpr int UPD_K1 = 256, UPD_LD1 = UPD_K1 + 2, UPD_UO = 384, UPD_AT_LD = UPD_UO + 4, UPD_F = 128;
+constexpr int UPD_LDS_FLOATS = 16 * UPD_LD1 + 16 * MID_LD + 16 * UPD_AT_LD + 8 * 16 * UPD_F;
+
+__global__ __launch_bounds__(512, 1) void painn_update_chain_kernel(UpdateArgs a) {
+  extern __shared__ __align__(16) float upd_lds[];
+  float* Xa = upd_lds;                    // [16][LD1]   c tile
+  float* Xb = Xa + 16 * UPD_LD1;          // [16][MID_LD] hidden tile
+  float* At = Xb + 16 * MID_LD;           // [16][AT_LD] output tile a
+  float* St = At + 16 * UPD_AT_LD;        // [8][16][F]  z, prod, v_u[0..2], v[0..2] of the tile
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = tid >> 6;
+  const int nblocks = gridDim.x;
+  const int er = tid >> 5, ef = 4 * (tid & 31);   // element-wise part: node er of the tile, features ef .. ef + 3
+
+  // (named registers, no arrays: a loop-carried float4 array captured by the lambda stays on the stack - and a kernel
+  //  with a scratch segment pays for it at every launch)
+  float4 zq, vu0, vu1, vu2, vv0, vv1, vv2, vq0, vq1, vq2;
+  auto tile_load = [&](int t) {
+    const int64_t row = static_cast<int64_t>(t) * 16 + er;
+    const bool in = t < a.ntiles && row < a.N;
+    const int64_t rs = in ? row : 0;    // (clamped: the loads are unconditional, the results of padding rows unused)
+    zq = *reinterpret_cast<const float4*>(a.zp + rs * UPD_F + ef);
+    vu0 = *reinterpret_cast<const float4*>(a.uv + ((rs * 3 + 0) * 2) * UPD_F + ef);
+    vv0 = *reinterpret_cast<const float4*>(a.uv + ((rs * 3 + 0) * 2 + 1) * UPD_F + ef);
+    vu1 = *reinterpret_cast<const float4*>(a.uv + ((rs * 3 + 1) * 2) * UPD_F + ef);
+    vv1 = *reinterpret_cast<const float4*>(a.uv + ((rs * 3 + 1) * 2 + 1) * UPD_F + ef);
+    vu2 = *reinterpret_cast<const float4*>(a.uv + ((rs * 3 + 2) * 2) * UPD_F + ef);
+    vv2 = *reinterpret_cast<const float4*>(a.uv + ((rs * 3 + 2) * 2 + 1) * UPD_F + ef);
+    vq0 = *reinterpret_cast<const float4*>(a.vp + (rs * 3 + 0) * UPD_F + ef);
+    vq1 = *reinterpret_cast<const float4*>(a.vp + (rs * 3 + 1) * UPD_F + ef);
+    vq2 = *reinterpret_cast<const float4*>(a.vp + (rs * 3 + 2) * UPD_F + ef);
+  };
+  tile_load(blockIdx.x);   // first: the tile must not queue behind the weight loads
+
+  float w1[1][UPD_K1 / 4];
+  float w2[3][MID / 4];
+  load_slice<UPD_K1, 1>(a.W1, wave, lane, w1);
+  load_slice<MID, 3>(a.W2, wave, lane, w2);
+  float bias1[1], bias2[3];
+  bias1[0] = a.b1 ? a.b1[wave * (128 / WAVES) + (lane & 15)] : 0.0f;
+#pragma unroll
+  for (int cb = 0; cb < 3; ++cb) bias2[cb] = a.b2 ? a.b2[wave * (UPD_UO / WAVES) + 16 * cb + (lane & 15)] : 0.0f;
+
+  for (int tile = blockIdx.x; tile < a.ntiles; tile += nblocks) {
+    const int64_t row0 = static_cast<int64_t>(tile) * 16;
+    const int64_t erow = row0 + er;
+    // ---- pre (painn_update_pre_kernel's arithmetic, k order) ----
+    const float4 vu[3] = {vu0, vu1, vu2}, vv[3] = {vv0, vv1, vv2}, vq[3] = {vq0, vq1, vq2};
+    float pr[4] = {0.f, 0.f, 0.f, 0.f}, sq[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+      pr[0] += vu[k].x * vv[k].x; sq[0] += vv[k].x * vv[k].x;
+      pr[1] += vu[k].y * vv[k].y; sq[1] += vv[k].y * vv[k].y;
+      pr[2] += vu[k].z * vv[k].z; sq[2] += vv[k].z * vv[k].z;
+      pr[3] += vu[k].w * vv[k].w; sq[3] += vv[k].w * vv[k].w;
+    }
+    const float4 prod4 = make_float4(pr[0], pr[1], pr[2], pr[3]);
+    const float4 nrm4 = make_float4(sqrtf(fmaxf(sq[0], 0.0f)), sqrtf(fmaxf(sq[1], 0.0f)), sqrtf(fmaxf(sq[2], 0.0f)),
+                                    sqrtf(fmaxf(sq[3], 0.0f)));
+    {
+      float* d = Xa + er * UPD_LD1 + ef;           // (LD1 = 258: 8-B aligned rows - scalar stores)
+      d[0] = zq.x; d[1] = zq.y; d[2] = zq.z; d[3] = zq.w;
+      d[UPD_F + 0] = nrm4.x; d[UPD_F + 1] = nrm4.y; d[UPD_F + 2] = nrm4.z; d[UPD_F + 3] = nrm4.w;
+      float4* st = reinterpret_cast<float4*>(St + er * UPD_F + ef);
+      st[0] = zq;
+      st[(16 * UPD_F / 4) * 1] = prod4;
+#pragma unroll
+      for (int k = 0; k < 3; ++k) {
+        st[(16 * UPD_F / 4) * (2 + k)] = vu[k];
+        st[(16 * UPD_F / 4) * (5 + k)] = vq[k];
+      }
+      if (erow < a.N) {
+        if (a.c_out) {
+          *reinterpret_cast<float4*>(a.c_out + erow * 2 * UPD_F + ef) = zq;
+          *reinterpret_cast<float4*>(a.c_out + erow * 2 * UPD_F + UPD_F + ef) = nrm4;
+        }
+        if (a.prod_out) *reinterpret_cast<float4*>(a.prod_out + erow * UPD_F + ef) = prod4;
+      }
+    }
+    __syncthreads();
+    // ---- chain: hidden = act(c W1 + b1), a = hidden W2 + b2 ----
+    floatx4 acc1[1];
+    acc1[0] = floatx4{0.f, 0.f, 0.f, 0.f};
+    gemm16<UPD_K1, UPD_LD1, 1>(Xa, lane, w1, acc1);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int lrow = 4 * (lane >> 4) + r;
+      const int64_t row = row0 + lrow;
+      const int col = wave * (128 / WAVES) + (lane & 15);
+      float v = acc1[0][r] + bias1[0];
+      if (a.save_pre && row < a.N) a.save_pre[row * 128 + col] = v;
+      Xb[lrow * MID_LD + col] = mp_apply_act(a.act1, a.alpha1, v);
+    }
+    __syncthreads();
+    floatx4 acc2[3];
+#pragma unroll
+    for (int cb = 0; cb < 3; ++cb) acc2[cb] = floatx4{0.f, 0.f, 0.f, 0.f};
+    gemm16<MID, MID_LD, 3>(Xb, lane, w2, acc2);
+#pragma unroll
+    for (int cb = 0; cb < 3; ++cb)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int lrow = 4 * (lane >> 4) + r;
+        const int64_t row = row0 + lrow;
+        const int col = wave * (UPD_UO / WAVES) + 16 * cb + (lane & 15);
+        const float v = acc2[cb][r] + bias2[cb];
+        At[lrow * UPD_AT_LD + col] = v;
+        if (a.a_out && row < a.N) a.a_out[row * UPD_UO + col] = v;
+      }
+    __syncthreads();
+    // ---- post (painn_update_post_kernel's arithmetic) ----
+    if (erow < a.N) {
+      const float4 a_vv = *reinterpret_cast<const float4*>(At + er * UPD_AT_LD + ef);
+      const float4 a_sv = *reinterpret_cast<const float4*>(At + er * UPD_AT_LD + UPD_F + ef);
+      const float4 a_ss = *reinterpret_cast<const float4*>(At + er * UPD_AT_LD + 2 * UPD_F + ef);
+      const float4* st = reinterpret_cast<const float4*>(St + er * UPD_F + ef);
+      const float4 z0 = st[0], p0 = st[(16 * UPD_F / 4) * 1];
+      *reinterpret_cast<float4*>(a.z2 + erow * UPD_F + ef) =
+          make_float4(z0.x + (p0.x * a_sv.x + a_ss.x), z0.y + (p0.y * a_sv.y + a_ss.y), z0.z + (p0.z * a_sv.z + a_ss.z),
+                      z0.w + (p0.w * a_sv.w + a_ss.w));
+#pragma unroll
+      for (int k = 0; k < 3; ++k) {
+        const float4 u = st[(16 * UPD_F / 4) * (2 + k)], v0 = st[(16 * UPD_F / 4) * (5 + k)];
+        *reinterpret_cast<float4*>(a.v2 + (erow * 3 + k) * UPD_F + ef) =
+            make_float4(v0.x + a_vv.x * u.x, v0.y + a_vv.y * u.y, v0.z + a_vv.z * u.z, v0.w + a_vv.w * u.w);
+      }
+    }
+    // next tile's rows: requested only now - 40 registers held across the GEMMs (next to 160 of weights) would spill,
+    // and a kernel with a scratch segment pays for it at every launch; at molecular batch sizes a workgroup has one tile
+    tile_load(tile + nblocks);
+    __syncthreads();   // the LDS tiles are reused by the next tile
+  }
+}
+
 // image element i = ((((w * ncb + cb) * (K/16) + q) * 64 + lane) * 4 + j  <-  W[4 (4q + j) + (lane >> 4)][w (U/8) + 16 cb + (lane & 15)]
 __global__ void chain_pack_kernel(const float* __restrict__ W, int K, int U, float* __restrict__ packed) {
   const int ncb = U / (16 * WAVES), total = K * U;
@@ -272,6 +442,36 @@ int mp_dense_chain_f32(const float* x, int64_t R, int K1, const float* W1_packed
   if (K1 == 128) return dispatch_chain<128>(a, ncb1, ncb2, s);
   if (K1 == 256) return dispatch_chain<256>(a, ncb1, ncb2, s);
   return dispatch_chain<384>(a, ncb1, ncb2, s);
+}
+
+int mp_painn_update_fused_f32(const float* z, const float* v, const float* uv, int64_t N, const float* W1_packed,
+                              const float* b1, int act1, float alpha1, float* save_pre, const float* W2_packed,
+                              const float* b2, float* c_out, float* prod_out, float* a_out, float* z2, float* v2,
+                              mpStream_t stream) {
+  MP_REQUIRE(N >= 0, "mp_painn_update_fused_f32: bad size");
+  MP_REQUIRE(act1 >= MP_ACT_LINEAR && act1 <= MP_ACT_LAST, "mp_painn_update_fused_f32: unknown activation %d", act1);
+  if (N == 0) return MP_OK;
+  MP_REQUIRE(z && v && uv && W1_packed && W2_packed && z2 && v2, "mp_painn_update_fused_f32: null pointer");
+  UpdateArgs a{};
+  a.N = N; a.ntiles = static_cast<int>((N + 15) / 16);
+  a.zp = z; a.vp = v; a.uv = uv; a.W1 = W1_packed; a.b1 = b1; a.act1 = act1; a.alpha1 = alpha1; a.save_pre = save_pre;
+  a.W2 = W2_packed; a.b2 = b2; a.c_out = c_out; a.prod_out = prod_out; a.a_out = a_out; a.z2 = z2; a.v2 = v2;
+  const size_t lds = sizeof(float) * UPD_LDS_FLOATS;
+  static std::mutex mu;                      // dynamic-LDS opt-in: per device, guarded
+  static unsigned long long done_mask = 0;
+  {
+    int dev = 0;
+    MP_HIP(hipGetDevice(&dev));
+    std::lock_guard<std::mutex> lock(mu);
+    if (dev >= 64 || !((done_mask >> dev) & 1ull)) {
+      MP_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&painn_update_chain_kernel),
+                                 hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds)));
+      if (dev < 64) done_mask |= 1ull << dev;
+    }
+  }
+  const int grid = a.ntiles < 256 ? a.ntiles : 256;
+  painn_update_chain_kernel<<<grid, 512, lds, mp::as_stream(stream)>>>(a);
+  return mp::check_launch("mp_painn_update_fused_f32");
 }
 
 }  // extern "C"

@@ -327,7 +327,9 @@ __device__ __forceinline__ void schnet_node_body(const NodeArgs& a, int block, i
 }
 
 template <int MODE, int E, int RB, bool FAST, bool PACKED, bool SAVE>
-__global__ __launch_bounds__(256, MODE != NODE_LAST ? 2 : 1) void schnet_node_kernel(NodeArgs a) {
+// (the SAVE builds of the energy + force pass need a few registers more than 256: one workgroup per CU instead of a
+// scratch segment, which every launch of the kernel would pay for)
+__global__ __launch_bounds__(256, (MODE != NODE_LAST && !SAVE) ? 2 : 1) void schnet_node_kernel(NodeArgs a) {
   schnet_node_body<MODE, E, RB, FAST, PACKED, SAVE>(a, blockIdx.x, gridDim.x);
 }
 

@@ -205,12 +205,14 @@ class FusedPainn:
                       _ffi.ptr(self.ptr0), _ffi.ptr(self.perm0), _ffi.ptr(self.send), m, _ffi.ptr(z), _ffi.ptr(t["zp"]),
                       _ffi.ptr(t["vp"]), _ffi.stream())
             self._chain(t["vp"], 3 * n, 128, w["uv%d/P" % i], None, 256, t["uv"])
-            _ffi.call("mp_painn_update_pre_f32", _ffi.ptr(t["zp"]), _ffi.ptr(t["uv"]), n, _ffi.ptr(t["c"]),
-                      _ffi.ptr(t["prod"]), _ffi.stream())
-            self._chain(t["c"], n, 256, w[u + "dense1/P"], p.get(u + "dense1/bias"), 128, t["a"], act=self.act_upd,
-                        save_pre=t["h2"] if self.grad else None, w2=w[u + "a/P"], b2=p.get(u + "a/bias"), u2=384)
-            _ffi.call("mp_painn_update_post_f32", _ffi.ptr(t["zp"]), _ffi.ptr(t["vp"]), _ffi.ptr(t["uv"]),
-                      _ffi.ptr(t["prod"]), _ffi.ptr(t["a"]), n, _ffi.ptr(z_out), _ffi.ptr(v_out), _ffi.stream())
+            # PAiNNUpdate's element-wise steps (norm / scalar product before, the gated residual updates after) are the
+            # prologue and the epilogue of its two-layer chain: one launch; c, prod, a reach HBM for the reverse pass only
+            g = self.grad
+            _ffi.call("mp_painn_update_fused_f32", _ffi.ptr(t["zp"]), _ffi.ptr(t["vp"]), _ffi.ptr(t["uv"]), n,
+                      _ffi.ptr(w[u + "dense1/P"]), _ffi.ptr(p.get(u + "dense1/bias")), self.act_upd, 0.0,
+                      _ffi.ptr(t["h2"]) if g else None, _ffi.ptr(w[u + "a/P"]), _ffi.ptr(p.get(u + "a/bias")),
+                      _ffi.ptr(t["c"]) if g else None, _ffi.ptr(t["prod"]) if g else None,
+                      _ffi.ptr(t["a"]) if g else None, _ffi.ptr(z_out), _ffi.ptr(v_out), _ffi.stream())
             z, v = z_out, v_out
         if self.fast_readout:   # PoolingNodes(sum) + MLP([H, 1]) - and, for forces, dE/dz of the readout - in one launch
             _ffi.call("mp_pool_mlp2_f32", _ffi.ptr(z), _ffi.ptr(node.row_splits), self.G, 128,

@@ -330,6 +330,13 @@ int mp_painn_message_bwd_f32(const float* s, const float* v, int64_t N, const fl
  * post: z2 = z + prod a_sv + a_ss, v2 = v + a_vv (x) v_u  with a (N,3F) = [a_vv | a_sv | a_ss] (+ PAiNN.py:131-132);
  * post_bwd: g_a (N,3F), g_prod (N,F) from g_z2, g_v2;  pre_bwd: g_z = g_z2 + g_c[:, :F], g_uv (3N,2F). */
 int mp_painn_update_pre_f32(const float* z, const float* uv, int64_t N, float* c, float* prod, mpStream_t stream);
+/* pre + Dense(act) + Dense + post of one PAiNNUpdate in ONE launch (csrc/mp_chain.hip): the element-wise steps as
+ * prologue / epilogue of the two-layer chain (W1 (256,128), W2 (128,384) as mp_chain_pack_f32 images).  save_pre keeps
+ * c Wd + bd; c_out / prod_out / a_out (any may be NULL) receive what the reverse pass reads. */
+int mp_painn_update_fused_f32(const float* z, const float* v, const float* uv, int64_t N, const float* W1_packed,
+                              const float* b1, int act1, float alpha1, float* save_pre, const float* W2_packed,
+                              const float* b2, float* c_out, float* prod_out, float* a_out, float* z2, float* v2,
+                              mpStream_t stream);
 int mp_painn_update_post_f32(const float* z, const float* v, const float* uv, const float* prod, const float* a,
                              int64_t N, float* z2, float* v2, mpStream_t stream);
 int mp_painn_update_post_bwd_f32(const float* g_z2, const float* g_v2, const float* uv, const float* prod,
