@@ -352,6 +352,152 @@ __global__ __launch_bounds__(512, 1) void painn_update_chain_kernel(UpdateArgs a
   }
 }
 
+// Reverse of the fused PAiNNUpdate above, one launch per block (replaces painn_update_post_bwd / painn_update_pre_bwd of
+// csrc/mp_painn_fused.hip around the <384, 1, 2> reverse chain):
+//   prologue  g_a = [sum_k g_v2[k] v_u[k] | g_z2 prod | g_z2] ,  g_prod = g_z2 a_sv
+//   chain     g_c = ((g_a Wa^T) * act'(h2)) Wd^T                                   (N, 2F)
+//   epilogue  g_z = g_z2 + g_c[:, :F] ,  g_vu[k] = g_v2[k] a_vv + g_prod v_v[k] ,  g_vv[k] = g_prod v_u[k] + g_c[:, F:] v_v[k] / ||v_v||
+// Same arithmetic, same order as the separate kernels; everything the epilogue needs again waits in LDS (13 x 8 KB).
+struct UpdateBwdArgs {
+  int64_t N;
+  int ntiles;
+  const float* gz2;       // (N, F)
+  const float* gv2;       // (N, 3, F)
+  const float* uv;        // (3N, 2F)
+  const float* prod;      // (N, F)
+  const float* a;         // (N, 3F)
+  const float* c;         // (N, 2F)  (the norm half is read)
+  const float* W1;        // packed (384, 128) = Wa^T
+  int act1;
+  float alpha1;
+  const float* grad_pre;  // (N, 128) h2
+  const float* W2;        // packed (128, 256) = Wd^T
+  float* g_zp;            // (N, F)
+  float* g_uv;            // (3N, 2F)
+};
+
+constexpr int UB_K1 = 384, UB_LD1 = UB_K1 + 2, UB_UO = 256, UB_GT_LD = UB_UO + 4;
+constexpr int UB_NST = 13;
+constexpr int UB_LDS_FLOATS = 16 * UB_LD1 + 16 * MID_LD + 16 * UB_GT_LD + UB_NST * 16 * UPD_F;
+
+__global__ __launch_bounds__(512, 1) void painn_update_bwd_chain_kernel(UpdateBwdArgs a) {
+  extern __shared__ __align__(16) float upd_lds[];
+  float* Xa = upd_lds;                    // [16][LD1]    g_a tile
+  float* Xb = Xa + 16 * UB_LD1;           // [16][MID_LD]
+  float* Gt = Xb + 16 * MID_LD;           // [16][GT_LD]  g_c tile
+  float* St = Gt + 16 * UB_GT_LD;         // [13][16][F]: g_z2, g_v2[0..2], v_u[0..2], v_v[0..2], norm, a_vv, g_prod
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = tid >> 6;
+  const int nblocks = gridDim.x;
+  const int er = tid >> 5, ef = 4 * (tid & 31);
+  constexpr int SL = 16 * UPD_F / 4;      // float4 per stash slice
+
+  float4 gz, gv0, gv1, gv2, vu0, vu1, vu2, vv0, vv1, vv2, pq, asv, avv, nq;
+  auto tile_load = [&](int t) {
+    const int64_t row = static_cast<int64_t>(t) * 16 + er;
+    const bool in = t < a.ntiles && row < a.N;
+    const int64_t rs = in ? row : 0;
+    gz = *reinterpret_cast<const float4*>(a.gz2 + rs * UPD_F + ef);
+    gv0 = *reinterpret_cast<const float4*>(a.gv2 + (rs * 3 + 0) * UPD_F + ef);
+    gv1 = *reinterpret_cast<const float4*>(a.gv2 + (rs * 3 + 1) * UPD_F + ef);
+    gv2 = *reinterpret_cast<const float4*>(a.gv2 + (rs * 3 + 2) * UPD_F + ef);
+    vu0 = *reinterpret_cast<const float4*>(a.uv + ((rs * 3 + 0) * 2) * UPD_F + ef);
+    vv0 = *reinterpret_cast<const float4*>(a.uv + ((rs * 3 + 0) * 2 + 1) * UPD_F + ef);
+    vu1 = *reinterpret_cast<const float4*>(a.uv + ((rs * 3 + 1) * 2) * UPD_F + ef);
+    vv1 = *reinterpret_cast<const float4*>(a.uv + ((rs * 3 + 1) * 2 + 1) * UPD_F + ef);
+    vu2 = *reinterpret_cast<const float4*>(a.uv + ((rs * 3 + 2) * 2) * UPD_F + ef);
+    vv2 = *reinterpret_cast<const float4*>(a.uv + ((rs * 3 + 2) * 2 + 1) * UPD_F + ef);
+    pq = *reinterpret_cast<const float4*>(a.prod + rs * UPD_F + ef);
+    avv = *reinterpret_cast<const float4*>(a.a + rs * 3 * UPD_F + ef);
+    asv = *reinterpret_cast<const float4*>(a.a + rs * 3 * UPD_F + UPD_F + ef);
+    nq = *reinterpret_cast<const float4*>(a.c + rs * 2 * UPD_F + UPD_F + ef);
+  };
+  tile_load(blockIdx.x);
+
+  float w1[1][UB_K1 / 4];
+  float w2[2][MID / 4];
+  load_slice<UB_K1, 1>(a.W1, wave, lane, w1);
+  load_slice<MID, 2>(a.W2, wave, lane, w2);
+
+  for (int tile = blockIdx.x; tile < a.ntiles; tile += nblocks) {
+    const int64_t row0 = static_cast<int64_t>(tile) * 16;
+    const int64_t erow = row0 + er;
+    // ---- prologue (painn_update_post_bwd_kernel's arithmetic) ----
+    const float4 gavv = make_float4((0.0f + gv0.x * vu0.x + gv1.x * vu1.x) + gv2.x * vu2.x,
+                                    (0.0f + gv0.y * vu0.y + gv1.y * vu1.y) + gv2.y * vu2.y,
+                                    (0.0f + gv0.z * vu0.z + gv1.z * vu1.z) + gv2.z * vu2.z,
+                                    (0.0f + gv0.w * vu0.w + gv1.w * vu1.w) + gv2.w * vu2.w);
+    const float4 gasv = make_float4(gz.x * pq.x, gz.y * pq.y, gz.z * pq.z, gz.w * pq.w);
+    const float4 gprod = make_float4(gz.x * asv.x, gz.y * asv.y, gz.z * asv.z, gz.w * asv.w);
+    {
+      float* d = Xa + er * UB_LD1 + ef;
+      d[0] = gavv.x; d[1] = gavv.y; d[2] = gavv.z; d[3] = gavv.w;
+      d[UPD_F + 0] = gasv.x; d[UPD_F + 1] = gasv.y; d[UPD_F + 2] = gasv.z; d[UPD_F + 3] = gasv.w;
+      d[2 * UPD_F + 0] = gz.x; d[2 * UPD_F + 1] = gz.y; d[2 * UPD_F + 2] = gz.z; d[2 * UPD_F + 3] = gz.w;
+      float4* st = reinterpret_cast<float4*>(St + er * UPD_F + ef);
+      st[SL * 0] = gz;
+      st[SL * 1] = gv0; st[SL * 2] = gv1; st[SL * 3] = gv2;
+      st[SL * 4] = vu0; st[SL * 5] = vu1; st[SL * 6] = vu2;
+      st[SL * 7] = vv0; st[SL * 8] = vv1; st[SL * 9] = vv2;
+      st[SL * 10] = nq; st[SL * 11] = avv; st[SL * 12] = gprod;
+    }
+    __syncthreads();
+    // ---- chain: m = (g_a W1) * act'(h2), g_c = m W2 ----
+    float gp[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int64_t row = row0 + 4 * (lane >> 4) + r;
+      gp[r] = row < a.N ? a.grad_pre[row * 128 + wave * (128 / WAVES) + (lane & 15)] : 0.0f;
+    }
+    floatx4 acc1[1];
+    acc1[0] = floatx4{0.f, 0.f, 0.f, 0.f};
+    gemm16<UB_K1, UB_LD1, 1>(Xa, lane, w1, acc1);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int lrow = 4 * (lane >> 4) + r;
+      const int col = wave * (128 / WAVES) + (lane & 15);
+      Xb[lrow * MID_LD + col] = acc1[0][r] * mp_act_grad(a.act1, a.alpha1, gp[r]);
+    }
+    __syncthreads();
+    floatx4 acc2[2];
+#pragma unroll
+    for (int cb = 0; cb < 2; ++cb) acc2[cb] = floatx4{0.f, 0.f, 0.f, 0.f};
+    gemm16<MID, MID_LD, 2>(Xb, lane, w2, acc2);
+#pragma unroll
+    for (int cb = 0; cb < 2; ++cb)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int lrow = 4 * (lane >> 4) + r;
+        const int col = wave * (UB_UO / WAVES) + 16 * cb + (lane & 15);
+        Gt[lrow * UB_GT_LD + col] = acc2[cb][r];
+      }
+    __syncthreads();
+    // ---- epilogue (painn_update_pre_bwd_kernel's arithmetic) ----
+    if (erow < a.N) {
+      const float4 gc0 = *reinterpret_cast<const float4*>(Gt + er * UB_GT_LD + ef);
+      const float4 gc1 = *reinterpret_cast<const float4*>(Gt + er * UB_GT_LD + UPD_F + ef);
+      const float4* st = reinterpret_cast<const float4*>(St + er * UPD_F + ef);
+      const float4 z0 = st[SL * 0], nrm = st[SL * 10], a_vv = st[SL * 11], gpd = st[SL * 12];
+      *reinterpret_cast<float4*>(a.g_zp + erow * UPD_F + ef) = make_float4(z0.x + gc0.x, z0.y + gc0.y, z0.z + gc0.z, z0.w + gc0.w);
+      const float4 inv = make_float4(nrm.x > 0.0f ? gc1.x / nrm.x : 0.0f, nrm.y > 0.0f ? gc1.y / nrm.y : 0.0f,
+                                     nrm.z > 0.0f ? gc1.z / nrm.z : 0.0f, nrm.w > 0.0f ? gc1.w / nrm.w : 0.0f);
+#pragma unroll
+      for (int k = 0; k < 3; ++k) {
+        const float4 g2 = st[SL * (1 + k)], u = st[SL * (4 + k)], v = st[SL * (7 + k)];
+        *reinterpret_cast<float4*>(a.g_uv + ((erow * 3 + k) * 2) * UPD_F + ef) =
+            make_float4(g2.x * a_vv.x + gpd.x * v.x, g2.y * a_vv.y + gpd.y * v.y, g2.z * a_vv.z + gpd.z * v.z,
+                        g2.w * a_vv.w + gpd.w * v.w);
+        *reinterpret_cast<float4*>(a.g_uv + ((erow * 3 + k) * 2 + 1) * UPD_F + ef) =
+            make_float4(gpd.x * u.x + inv.x * v.x, gpd.y * u.y + inv.y * v.y, gpd.z * u.z + inv.z * v.z,
+                        gpd.w * u.w + inv.w * v.w);
+      }
+    }
+    tile_load(tile + nblocks);
+    __syncthreads();
+  }
+}
+
 // image element i = ((((w * ncb + cb) * (K/16) + q) * 64 + lane) * 4 + j  <-  W[4 (4q + j) + (lane >> 4)][w (U/8) + 16 cb + (lane & 15)]
 __global__ void chain_pack_kernel(const float* __restrict__ W, int K, int U, float* __restrict__ packed) {
   const int ncb = U / (16 * WAVES), total = K * U;
@@ -472,6 +618,37 @@ int mp_painn_update_fused_f32(const float* z, const float* v, const float* uv, i
   const int grid = a.ntiles < 256 ? a.ntiles : 256;
   painn_update_chain_kernel<<<grid, 512, lds, mp::as_stream(stream)>>>(a);
   return mp::check_launch("mp_painn_update_fused_f32");
+}
+
+int mp_painn_update_fused_bwd_f32(const float* g_z2, const float* g_v2, const float* uv, const float* prod, const float* a,
+                                  const float* c, int64_t N, const float* W1T_packed, int act1, float alpha1,
+                                  const float* grad_pre, const float* W2T_packed, float* g_z, float* g_uv,
+                                  mpStream_t stream) {
+  MP_REQUIRE(N >= 0, "mp_painn_update_fused_bwd_f32: bad size");
+  MP_REQUIRE(act1 >= MP_ACT_LINEAR && act1 <= MP_ACT_LAST, "mp_painn_update_fused_bwd_f32: unknown activation %d", act1);
+  if (N == 0) return MP_OK;
+  MP_REQUIRE(g_z2 && g_v2 && uv && prod && a && c && W1T_packed && grad_pre && W2T_packed && g_z && g_uv,
+             "mp_painn_update_fused_bwd_f32: null pointer");
+  UpdateBwdArgs q{};
+  q.N = N; q.ntiles = static_cast<int>((N + 15) / 16);
+  q.gz2 = g_z2; q.gv2 = g_v2; q.uv = uv; q.prod = prod; q.a = a; q.c = c; q.W1 = W1T_packed; q.act1 = act1;
+  q.alpha1 = alpha1; q.grad_pre = grad_pre; q.W2 = W2T_packed; q.g_zp = g_z; q.g_uv = g_uv;
+  const size_t lds = sizeof(float) * UB_LDS_FLOATS;
+  static std::mutex mu;                      // dynamic-LDS opt-in: per device, guarded
+  static unsigned long long done_mask = 0;
+  {
+    int dev = 0;
+    MP_HIP(hipGetDevice(&dev));
+    std::lock_guard<std::mutex> lock(mu);
+    if (dev >= 64 || !((done_mask >> dev) & 1ull)) {
+      MP_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&painn_update_bwd_chain_kernel),
+                                 hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds)));
+      if (dev < 64) done_mask |= 1ull << dev;
+    }
+  }
+  const int grid = q.ntiles < 256 ? q.ntiles : 256;
+  painn_update_bwd_chain_kernel<<<grid, 512, lds, mp::as_stream(stream)>>>(q);
+  return mp::check_launch("mp_painn_update_fused_bwd_f32");
 }
 
 }  // extern "C"

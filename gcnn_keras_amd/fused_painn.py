@@ -252,13 +252,11 @@ class FusedPainn:
             c, u = "conv%d/" % i, "update%d/" % i
             b = self.blk[i]
             v_in = self.v0 if i == 0 else self.vs[i - 1]
-            _ffi.call("mp_painn_update_post_bwd_f32", _ffi.ptr(self.gz), _ffi.ptr(self.gv), _ffi.ptr(b["uv"]),
-                      _ffi.ptr(b["prod"]), _ffi.ptr(b["a"]), n, _ffi.ptr(self.g_a), _ffi.ptr(self.g_prod), _ffi.stream())
-            self._chain(self.g_a, n, 384, w[u + "a/TP"], None, 128, self.g_c, act=self.act_upd, grad_pre=b["h2"],
-                        w2=w[u + "dense1/TP"], u2=256)
-            _ffi.call("mp_painn_update_pre_bwd_f32", _ffi.ptr(self.gz), _ffi.ptr(self.gv), _ffi.ptr(b["uv"]),
-                      _ffi.ptr(b["c"]), _ffi.ptr(b["a"]), _ffi.ptr(self.g_prod), _ffi.ptr(self.g_c), n,
-                      _ffi.ptr(self.g_zp), _ffi.ptr(self.g_uv), _ffi.stream())
+            # reverse of the fused PAiNNUpdate: post_bwd / pre_bwd as prologue / epilogue of the transposed chain
+            _ffi.call("mp_painn_update_fused_bwd_f32", _ffi.ptr(self.gz), _ffi.ptr(self.gv), _ffi.ptr(b["uv"]),
+                      _ffi.ptr(b["prod"]), _ffi.ptr(b["a"]), _ffi.ptr(b["c"]), n, _ffi.ptr(w[u + "a/TP"]), self.act_upd,
+                      0.0, _ffi.ptr(b["h2"]), _ffi.ptr(w[u + "dense1/TP"]), _ffi.ptr(self.g_zp), _ffi.ptr(self.g_uv),
+                      _ffi.stream())
             self._chain(self.g_uv, 3 * n, 256, w["uvT%d/P" % i], None, 128, self.g_vp, addend=self.gv)
             _ffi.call("mp_painn_message_bwd_f32", _ffi.ptr(b["s"]), _ffi.ptr(v_in), n, _ffi.ptr(self.rbf),
                       _ffi.ptr(self.rbfd), self.B, _ffi.ptr(self.env), _ffi.ptr(self.envd), _ffi.ptr(self.rij),
