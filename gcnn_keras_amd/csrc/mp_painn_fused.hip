@@ -25,6 +25,18 @@
 namespace {
 
 constexpr int F = 128;
+using floatx2 = __attribute__((ext_vector_type(2))) float;
+
+// acc.lo += x.lo * w, acc.hi += x.hi * w with ONE weight register for both halves: v_pk_fma_f32 whose weight operand is a
+// register pair (w_k, w_k+1) and op_sel picks the same half for both result lanes - x is a scalar pair (two v_readlane
+// results).  The compiler's own packing of this pattern duplicates every weight into a (w, w) pair, and the doubled
+// register count costs these latency-bound kernels the occupancy they live on (measured: slower).  Same fused arithmetic.
+__device__ __forceinline__ void pk_fma_wlo(floatx2& acc, floatx2 x, floatx2 wpair) {
+  asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel_hi:[1,0,1]" : "+v"(acc) : "s"(x), "v"(wpair));
+}
+__device__ __forceinline__ void pk_fma_whi(floatx2& acc, floatx2 x, floatx2 wpair) {
+  asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[0,1,0] op_sel_hi:[1,1,1]" : "+v"(acc) : "s"(x), "v"(wpair));
+}
 
 __device__ __forceinline__ float ipow(float x, int n) {
   float r = 1.0f;
@@ -197,11 +209,15 @@ __global__ __launch_bounds__(256) void painn_message_kernel(PainnMsgArgs a) {
   const int64_t wave0 = (static_cast<int64_t>(mp_xcd_block(blockIdx.x, gridDim.x)) * blockDim.x + threadIdx.x) >> 6;
   const int half = __builtin_amdgcn_readfirstlane(static_cast<int>(wave0 & 1));   // nwaves is even: fixed per wave
   const int f0 = half * 64 + lane;                                                 // this lane's feature
-  float w[3][MAXB], bias[3];
+  floatx2 wp[3][MAXB / 2];   // (w[p][2 q], w[p][2 q + 1]): the weight operand of the packed FMAs below
+  float bias[3];
 #pragma unroll
   for (int p = 0; p < 3; ++p) {
 #pragma unroll
-    for (int k = 0; k < MAXB; ++k) w[p][k] = k < B ? a.Ww[k * 3 * F + p * F + f0] : 0.0f;
+    for (int q = 0; q < MAXB / 2; ++q) {
+      wp[p][q].x = 2 * q < B ? a.Ww[(2 * q) * 3 * F + p * F + f0] : 0.0f;
+      wp[p][q].y = 2 * q + 1 < B ? a.Ww[(2 * q + 1) * 3 * F + p * F + f0] : 0.0f;
+    }
     bias[p] = a.bw ? a.bw[p * F + f0] : 0.0f;
   }
   for (int64_t wv = wave0; wv < 2 * a.N; wv += nwaves) {
@@ -240,30 +256,42 @@ __global__ __launch_bounds__(256) void painn_message_kernel(PainnMsgArgs a) {
           meta[u] = lane < B + 4 ? *mp_ : 0.0f;
         }
 #pragma unroll
-        for (int u = 0; u < EC; ++u) {
+        for (int u = 0; u < EC; u += 2) {
           if (u0 + u < cnt) {   // wave-uniform
-            float f[3] = {0.0f, 0.0f, 0.0f};
+            // the filters of TWO edges as register pairs (f_u[p], f_u+1[p]): one packed FMA per basis function, part and
+            // edge pair with the scalar pair (rbf_k of edge u, of edge u + 1) - pk_fma_wlo / whi, same fused arithmetic, k
+            // ascending; the tail repeats the last edge (loads) and drops the second half below
+            floatx2 ff[3] = {{0.0f, 0.0f}, {0.0f, 0.0f}, {0.0f, 0.0f}};
 #pragma unroll
-            for (int k = 0; k < MAXB; ++k) {
-              if (k < B) {
-                const float x = readlane_f(meta[u], k);
+            for (int q = 0; q < MAXB / 2; ++q) {
+              if (2 * q < B) {
+                const floatx2 x0 = {readlane_f(meta[u], 2 * q), readlane_f(meta[u + 1], 2 * q)};
+                const floatx2 x1 = {readlane_f(meta[u], 2 * q + 1), readlane_f(meta[u + 1], 2 * q + 1)};
 #pragma unroll
-                for (int p = 0; p < 3; ++p) f[p] = fmaf(x, w[p][k], f[p]);
+                for (int p = 0; p < 3; ++p) {
+                  pk_fma_wlo(ff[p], x0, wp[p][q]);
+                  pk_fma_whi(ff[p], x1, wp[p][q]);
+                }
               }
             }
-            const float envv = a.env ? readlane_f(meta[u], B + 3) : 1.0f;
-            float sw[3];
 #pragma unroll
-            for (int p = 0; p < 3; ++p) {
-              float wv_ = f[p] + bias[p];            // Dense: x W + b
-              if (a.env) wv_ *= envv;                // lay_mult_cutoff([w, envelope])
-              sw[p] = sj[u][p] * wv_;                // lay_mult([s, w])
-            }
-            ds += sw[0];
+            for (int h = 0; h < 2; ++h) {
+              if (u0 + u + h < cnt) {   // wave-uniform
+                const float envv = a.env ? readlane_f(meta[u + h], B + 3) : 1.0f;
+                float sw[3];
 #pragma unroll
-            for (int k = 0; k < 3; ++k) {
-              const float rk = readlane_f(meta[u], B + k);
-              dv[k] += sw[1] * vj[u][k] + sw[2] * rk;   // (sw2 * v_j) + (sw3 * r_ij)
+                for (int p = 0; p < 3; ++p) {
+                  float wv_ = (h ? ff[p].y : ff[p].x) + bias[p];   // Dense: x W + b
+                  if (a.env) wv_ *= envv;                          // lay_mult_cutoff([w, envelope])
+                  sw[p] = sj[u + h][p] * wv_;                      // lay_mult([s, w])
+                }
+                ds += sw[0];
+#pragma unroll
+                for (int k = 0; k < 3; ++k) {
+                  const float rk = readlane_f(meta[u + h], B + k);
+                  dv[k] += sw[1] * vj[u + h][k] + sw[2] * rk;   // (sw2 * v_j) + (sw3 * r_ij)
+                }
+              }
             }
           }
         }
@@ -324,11 +352,15 @@ __global__ __launch_bounds__(256) void painn_message_bwd_kernel(PainnMsgBwdArgs 
   const int f0 = half * 64 + lane;
   float* const g_d = a.g_d + static_cast<int64_t>(half) * a.M;
   float* const g_rij = a.g_rij + static_cast<int64_t>(half) * a.M * 3;
-  float w[3][MAXB], bias[3];
+  floatx2 wp[3][MAXB / 2];   // (w[p][2 q], w[p][2 q + 1]): the weight operand of the packed FMAs below
+  float bias[3];
 #pragma unroll
   for (int p = 0; p < 3; ++p) {
 #pragma unroll
-    for (int k = 0; k < MAXB; ++k) w[p][k] = k < B ? a.Ww[k * 3 * F + p * F + f0] : 0.0f;
+    for (int q = 0; q < MAXB / 2; ++q) {
+      wp[p][q].x = 2 * q < B ? a.Ww[(2 * q) * 3 * F + p * F + f0] : 0.0f;
+      wp[p][q].y = 2 * q + 1 < B ? a.Ww[(2 * q + 1) * 3 * F + p * F + f0] : 0.0f;
+    }
     bias[p] = a.bw ? a.bw[p * F + f0] : 0.0f;
   }
   for (int64_t wv = wave0; wv < 2 * a.N; wv += nwaves) {
@@ -372,18 +404,22 @@ __global__ __launch_bounds__(256) void painn_message_bwd_kernel(PainnMsgBwdArgs 
         for (int u = 0; u < EC; ++u) {
           if (u0 + u < cnt) {   // wave-uniform
             const int r = __builtin_amdgcn_readlane(my_r, u0 + u);
-            float f[3] = {0.0f, 0.0f, 0.0f}, fd[3] = {0.0f, 0.0f, 0.0f};
+            // (f[p], fd[p]) as one register pair: three packed FMAs per basis function instead of six (pk_fma_wlo / whi);
+            // k ascending as before.  For odd B the last pair's second weight is 0 (its scalar is a finite lane of meta).
+            floatx2 ff[3] = {{0.0f, 0.0f}, {0.0f, 0.0f}, {0.0f, 0.0f}};
 #pragma unroll
-            for (int k = 0; k < MAXB; ++k) {
-              if (k < B) {
-                const float x = readlane_f(meta[u], k), xd = readlane_f(metad[u], k);
+            for (int q = 0; q < MAXB / 2; ++q) {
+              if (2 * q < B) {
+                const floatx2 x0 = {readlane_f(meta[u], 2 * q), readlane_f(metad[u], 2 * q)};
+                const floatx2 x1 = {readlane_f(meta[u], 2 * q + 1), readlane_f(metad[u], 2 * q + 1)};
 #pragma unroll
                 for (int p = 0; p < 3; ++p) {
-                  f[p] = fmaf(x, w[p][k], f[p]);
-                  fd[p] = fmaf(xd, w[p][k], fd[p]);
+                  pk_fma_wlo(ff[p], x0, wp[p][q]);
+                  pk_fma_whi(ff[p], x1, wp[p][q]);
                 }
               }
             }
+            const float f[3] = {ff[0].x, ff[1].x, ff[2].x}, fd[3] = {ff[0].y, ff[1].y, ff[2].y};
             float rk[3];
 #pragma unroll
             for (int k = 0; k < 3; ++k) rk[k] = readlane_f(meta[u], B + k);
