@@ -97,6 +97,7 @@ _SIGNATURES = {
     "mp_painn_update_pre_bwd_f32": [P, P, P, P, P, P, P, c_int64, P, P, P],
     "mp_edge_geometry_bwd_f32": [P, P, c_int, P, P, P, P, P, P, c_int64, c_int64, c_float, P, P],
     "mp_schnet_node_pack_f32": [P, c_int, c_int, P, P],
+    "mp_schnet_node_pack_bf16_f32": [P, c_int, c_int, P, P],
     "mp_schnet_node_residual_f32": [P, c_int64, P, P, P, P, P, P, c_int, P],
     "mp_schnet_node_in_f32": [P, c_int64, P, c_int, c_int, P, P, P, P, P, c_int, P],
     "mp_schnet_stage0_f32": [P, c_int64, P, c_int, c_int, P, P, P, P, P, P, c_int64, P, P, c_int64, P, P, P, P, P, c_int,

@@ -76,6 +76,70 @@ __device__ __forceinline__ void gemm_tile(const float* __restrict__ Xs, int lane
   }
 }
 
+// ---- the same GEMMs on the bf16 matrix pipe as an exact FP32 emulation (csrc/mp_cfconv.hip: every operand split into
+//      three bf16 pieces, the six leading cross products on v_mfma_f32_16x16x32_bf16, FP32 accumulate) ----------------------
+using bf16x8 = __attribute__((ext_vector_type(8))) __bf16;
+using bf16x2 = __attribute__((ext_vector_type(2))) __bf16;
+using floatx2n = __attribute__((ext_vector_type(2))) float;
+
+// a wave's slice of W as B operands: [column block][k block of 32][piece], 16 B each (lane: column lane & 15, k group
+// lane >> 4 holds k = 32 kb + 8 (lane >> 4) + 0..7), from the image of mp_schnet_node_pack_bf16_f32
+template <int K, int NCB>
+struct WSliceBf {
+  bf16x8 p[NCB][K / 32][3];
+};
+template <int K, int NCB>
+__device__ __forceinline__ void load_w_bf(const float* __restrict__ P, int wave, int lane, WSliceBf<K, NCB>& w) {
+  const uint4* p4 = reinterpret_cast<const uint4*>(P);
+#pragma unroll
+  for (int cb = 0; cb < NCB; ++cb)
+#pragma unroll
+    for (int kb = 0; kb < K / 32; ++kb)
+#pragma unroll
+      for (int pc = 0; pc < 3; ++pc)
+        w.p[cb][kb][pc] = __builtin_bit_cast(bf16x8, p4[(((wave * NCB + cb) * (K / 32) + kb) * 3 + pc) * 64 + lane]);
+}
+
+// acc[rb][cb] += Xs(16*RB x K) @ Wslice.  A operand: lane (node lane & 15, k group lane >> 4) reads its 8 values of the
+// k block from the FP32 LDS tile and splits them in registers (value pairs: v_cvt_pk_bf16_f32, widen, packed subtract).
+template <int K, int NCB, int RB>
+__device__ __forceinline__ void gemm_tile_bf(const float* __restrict__ Xs, int lane, const WSliceBf<K, NCB>& w,
+                                             floatx4 (&acc)[RB][NCB]) {
+  const float* xp = Xs + (lane & 15) * X_LD + 8 * (lane >> 4);
+#pragma unroll
+  for (int kb = 0; kb < K / 32; ++kb) {
+#pragma unroll
+    for (int rb = 0; rb < RB; ++rb) {
+      uint4 hi, mid, lo;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const floatx2n x = *reinterpret_cast<const floatx2n*>(xp + rb * 16 * X_LD + 32 * kb + 2 * j);   // 8-B aligned
+        const unsigned u0 = __builtin_bit_cast(unsigned, __builtin_convertvector(x, bf16x2));
+        const floatx2n r1 = x - floatx2n{__uint_as_float(u0 << 16), __uint_as_float(u0 & 0xffff0000u)};
+        const unsigned u1 = __builtin_bit_cast(unsigned, __builtin_convertvector(r1, bf16x2));
+        const floatx2n r2 = r1 - floatx2n{__uint_as_float(u1 << 16), __uint_as_float(u1 & 0xffff0000u)};
+        const unsigned u2 = __builtin_bit_cast(unsigned, __builtin_convertvector(r2, bf16x2));
+        (j == 0 ? hi.x : j == 1 ? hi.y : j == 2 ? hi.z : hi.w) = u0;
+        (j == 0 ? mid.x : j == 1 ? mid.y : j == 2 ? mid.z : mid.w) = u1;
+        (j == 0 ? lo.x : j == 1 ? lo.y : j == 2 ? lo.z : lo.w) = u2;
+      }
+      const bf16x8 a_hi = __builtin_bit_cast(bf16x8, hi), a_mid = __builtin_bit_cast(bf16x8, mid),
+                   a_lo = __builtin_bit_cast(bf16x8, lo);
+#pragma unroll
+      for (int cb = 0; cb < NCB; ++cb) {   // smallest products first
+        floatx4 c = acc[rb][cb];
+        c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a_lo, w.p[cb][kb][0], c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a_hi, w.p[cb][kb][2], c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a_mid, w.p[cb][kb][1], c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a_mid, w.p[cb][kb][0], c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a_hi, w.p[cb][kb][1], c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a_hi, w.p[cb][kb][0], c, 0, 0, 0);
+        acc[rb][cb] = c;
+      }
+    }
+  }
+}
+
 // shifted softplus and its derivative sigmoid(x) from the same exponential: e = exp(-|x|), sigmoid = (x >= 0 ? 1 : e) / (1 + e)
 template <bool FAST>
 __device__ __forceinline__ float ssp_with_grad(float x, float& grad) {

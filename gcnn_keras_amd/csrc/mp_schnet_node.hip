@@ -13,6 +13,8 @@
 // once with coalesced 64-B reads), so the only LDS traffic is the 16x128 activation tile handed from one GEMM to
 // the next.  The MID / LAST kernels also re-zero the aggregation rows they consumed, so the next cfconv launch
 // needs no memset.
+#include <type_traits>
+
 #include "mp_common.h"
 #include "mp_edge_prepare.h"
 #include "mp_node_tile.h"
@@ -87,7 +89,9 @@ enum NodeMode { NODE_IN = 0, NODE_MID = 1, NODE_LAST = 2, NODE_UPD = 3 };
 
 // `block` / `nblocks`: this workgroup's position among the workgroups running the node chain (the stage-0 kernel runs
 // edge preparation on the remaining workgroups of the same launch).
-template <int MODE, int E, int RB, bool FAST, bool PACKED, bool SAVE = false>
+// BF: the GEMMs on the bf16 matrix pipe as an exact FP32 emulation (mp_node_tile.h: gemm_tile_bf), weights as
+// mp_schnet_node_pack_bf16_f32 images (three bf16 pieces per element: 1.5x the bytes, 2.67x the matrix rate).
+template <int MODE, int E, int RB, bool FAST, bool PACKED, bool SAVE = false, bool BF = false>
 __device__ __forceinline__ void schnet_node_body(const NodeArgs& a, int block, int nblocks) {
   __shared__ float Xa[16 * RB * X_LD];
   __shared__ float Xb[16 * RB * X_LD];
@@ -159,21 +163,30 @@ __device__ __forceinline__ void schnet_node_body(const NodeArgs& a, int block, i
   stage_load(block);
 
   // ---- weight slices -> registers (once per persistent workgroup) -------------------------------------------
-  float w_first[2][(MODE == NODE_IN ? E : F) / 4];   // IN: W0 ; MID/LAST: W2
-  float w_second[2][F / 4];                          // IN: Wx ; MID/LAST: W3
-  float w_third[2][((MODE == NODE_IN || MODE == NODE_UPD) ? 4 : F) / 4];   // MID: Wx ; LAST: Wl0
-  float w_fourth[1][(MODE == NODE_LAST ? F : 4) / 4];  // LAST: Wl1 (16 columns per wave)
+  constexpr int K1 = MODE == NODE_IN ? E : F;
+  constexpr int K3 = (MODE == NODE_IN || MODE == NODE_UPD) ? (BF ? 32 : 4) : F;   // (unused slices: smallest legal size)
+  constexpr int K4 = MODE == NODE_LAST ? F : (BF ? 32 : 4);
+  std::conditional_t<BF, WSliceBf<K1, 2>, float[2][K1 / 4]> w_first;    // IN: W0 ; MID/LAST: W2
+  std::conditional_t<BF, WSliceBf<F, 2>, float[2][F / 4]> w_second;     // IN: Wx ; MID/LAST: W3
+  std::conditional_t<BF, WSliceBf<K3, 2>, float[2][K3 / 4]> w_third;    // MID: Wx ; LAST: Wl0
+  std::conditional_t<BF, WSliceBf<K4, 1>, float[1][K4 / 4]> w_fourth;   // LAST: Wl1 (16 columns per wave)
   float bias_first[2], bias_second[2], bias_third[2], bias_fourth;
+#define MP_LOAD_W(KK, NCB, PTR, UU, DST)                                          \
+  if constexpr (BF) load_w_bf<KK, NCB>(PTR, wave, lane, DST);                     \
+  else load_w<KK, NCB, PACKED>(PTR, UU, wave, lane, DST)
+#define MP_GEMM(KK, NCB, XS, WW, ACC)                                             \
+  if constexpr (BF) gemm_tile_bf<KK, NCB, RB>(XS, lane, WW, ACC);                 \
+  else gemm_tile<KK, NCB, RB>(XS, lane, WW, ACC)
   if constexpr (MODE == NODE_IN) {
-    load_w<E, 2, PACKED>(a.W0, F, wave, lane, w_first);
-    load_w<F, 2, PACKED>(a.Wx, F, wave, lane, w_second);
+    MP_LOAD_W(E, 2, a.W0, F, w_first);
+    MP_LOAD_W(F, 2, a.Wx, F, w_second);
   } else {
-    load_w<F, 2, PACKED>(a.W2, F, wave, lane, w_first);
-    load_w<F, 2, PACKED>(a.W3, F, wave, lane, w_second);
-    if constexpr (MODE == NODE_MID) load_w<F, 2, PACKED>(a.Wx, F, wave, lane, w_third);
+    MP_LOAD_W(F, 2, a.W2, F, w_first);
+    MP_LOAD_W(F, 2, a.W3, F, w_second);
+    if constexpr (MODE == NODE_MID) { MP_LOAD_W(F, 2, a.Wx, F, w_third); }
     if constexpr (MODE == NODE_LAST) {
-      load_w<F, 2, PACKED>(a.Wl0, F, wave, lane, w_third);
-      load_w<F, 1, PACKED>(a.Wl1, 64, wave, lane, w_fourth);
+      MP_LOAD_W(F, 2, a.Wl0, F, w_third);
+      MP_LOAD_W(F, 1, a.Wl1, 64, w_fourth);
     }
   }
 #pragma unroll
@@ -222,7 +235,7 @@ __device__ __forceinline__ void schnet_node_body(const NodeArgs& a, int block, i
   _Pragma("unroll") for (int rb = 0; rb < RB; ++rb)              \
       _Pragma("unroll") for (int cb = 0; cb < 2; ++cb) acc[rb][cb] = floatx4{0.f, 0.f, 0.f, 0.f};
     MP_ZERO_ACC
-    gemm_tile<(MODE == NODE_IN ? E : F), 2, RB>(Xa, lane, w_first, acc);
+    MP_GEMM(K1, 2, Xa, w_first, acc);
     MP_NSTAMP(1)
     MP_FOR_OUT(cb, r, row, col, {
       float v = acc[rb][cb][r] + bias_first[cb];
@@ -249,7 +262,7 @@ __device__ __forceinline__ void schnet_node_body(const NodeArgs& a, int block, i
         n_res[rb][cb][r] = (node0 + row < a.N) ? a.n[(node0 + row) * F + col] : 0.0f;
       })
     }
-    gemm_tile<F, 2, RB>(Xb, lane, w_second, acc);
+    MP_GEMM(F, 2, Xb, w_second, acc);
     MP_NSTAMP(3)
     if constexpr (MODE == NODE_IN) {
       MP_FOR_OUT(cb, r, row, col, {
@@ -271,7 +284,7 @@ __device__ __forceinline__ void schnet_node_body(const NodeArgs& a, int block, i
       // ---- GEMM 3: MID: x = n @ Wx ; LAST: u = ssp(n @ Wl0 + bl0) ----------------------------------------------
       MP_ZERO_ACC
       if constexpr (LATE_STAGE) stage_load(tile + nblocks);
-      gemm_tile<F, 2, RB>(Xa, lane, w_third, acc);
+      MP_GEMM(K3, 2, Xa, w_third, acc);
       MP_NSTAMP(5)
       if constexpr (MODE == NODE_MID) {
         MP_FOR_OUT(cb, r, row, col, {
@@ -294,7 +307,7 @@ __device__ __forceinline__ void schnet_node_body(const NodeArgs& a, int block, i
         floatx4 acc4[RB][1];
 #pragma unroll
         for (int rb = 0; rb < RB; ++rb) acc4[rb][0] = floatx4{0.f, 0.f, 0.f, 0.f};
-        gemm_tile<F, 1, RB>(Xb, lane, w_fourth, acc4);
+        MP_GEMM(K4, 1, Xb, w_fourth, acc4);
 #pragma unroll
         for (int rb = 0; rb < RB; ++rb)
 #pragma unroll
@@ -324,22 +337,24 @@ __device__ __forceinline__ void schnet_node_body(const NodeArgs& a, int block, i
     for (int i = 0; i < 8; ++i) atomicAdd(&g_node_diag[i], dsum[i]);
   }
 #endif
+#undef MP_LOAD_W
+#undef MP_GEMM
 }
 
-template <int MODE, int E, int RB, bool FAST, bool PACKED, bool SAVE>
-// (the SAVE builds of the energy + force pass need a few registers more than 256: one workgroup per CU instead of a
-// scratch segment, which every launch of the kernel would pay for)
-__global__ __launch_bounds__(256, (MODE != NODE_LAST && !SAVE) ? 2 : 1) void schnet_node_kernel(NodeArgs a) {
-  schnet_node_body<MODE, E, RB, FAST, PACKED, SAVE>(a, blockIdx.x, gridDim.x);
+template <int MODE, int E, int RB, bool FAST, bool PACKED, bool SAVE, bool BF = false>
+// (the SAVE builds of the energy + force pass need a few registers more than 256, the bf16-piece builds hold 1.5x the
+// weight registers: one workgroup per CU instead of a scratch segment, which every launch of the kernel would pay for)
+__global__ __launch_bounds__(256, (MODE != NODE_LAST && !SAVE && !BF) ? 2 : 1) void schnet_node_kernel(NodeArgs a) {
+  schnet_node_body<MODE, E, RB, FAST, PACKED, SAVE, BF>(a, blockIdx.x, gridDim.x);
 }
 
 // Stage 0 of the fused forward: the node-input chain (Embedding -> Dense -> Dense_nobias) and the edge preparation
 // (index shift, receiver/sender split, flags, distance) are independent, and at QM9 batch sizes each alone fills less
 // than half of the chip for ~5 us - so one launch runs both, on disjoint workgroups (role by block index).
-template <int E, bool FAST, bool LDS_SPLITS, bool PACKED>
+template <int E, bool FAST, bool LDS_SPLITS, bool PACKED, bool BF = false>
 __global__ __launch_bounds__(256) void schnet_stage0_kernel(NodeArgs a, mp_prep::EdgePrepArgs p, int node_blocks) {
   if (static_cast<int>(blockIdx.x) < node_blocks) {
-    schnet_node_body<NODE_IN, E, 1, FAST, PACKED>(a, blockIdx.x, node_blocks);
+    schnet_node_body<NODE_IN, E, 1, FAST, PACKED, false, BF>(a, blockIdx.x, node_blocks);
   } else {
     mp_prep::edge_prepare_body<LDS_SPLITS>(p, static_cast<int64_t>(blockIdx.x) - node_blocks,
                                            static_cast<int64_t>(gridDim.x) - node_blocks);
@@ -430,11 +445,12 @@ __global__ __launch_bounds__(256) void schnet_readout_kernel(const float* __rest
 // serialisation was gone - 64-node tiles spill the weights, 32-node tiles spill ~25 registers whose reloads queue behind
 // the tile prefetch (3371 vs 3328 us per forward at 225 k nodes, 397 vs 380 us at 18 k).  The persistent grid is two
 // workgroups per CU.
-template <int MODE, int E, bool FAST, bool PACKED, bool SAVE = false>
+template <int MODE, int E, bool FAST, bool PACKED, bool SAVE = false, bool BF = false>
 int launch_node_impl(NodeArgs a, hipStream_t s, const char* what) {
   a.ntiles = static_cast<int>((a.N + 15) / 16);
-  const int grid = a.ntiles < 512 ? a.ntiles : 512;
-  schnet_node_kernel<MODE, E, 1, FAST, PACKED, SAVE><<<grid, 256, 0, s>>>(a);
+  const int cap = BF ? 256 : 512;   // bf16-piece builds: one workgroup per CU
+  const int grid = a.ntiles < cap ? a.ntiles : cap;
+  schnet_node_kernel<MODE, E, 1, FAST, PACKED, SAVE, BF><<<grid, 256, 0, s>>>(a);
   return mp::check_launch(what);
 }
 
@@ -454,12 +470,46 @@ __global__ void node_pack_kernel(const float* __restrict__ W, int K, int U, floa
   }
 }
 
+// bf16-piece image of a Keras kernel W (K, U), U = 64 * NCB, for load_w_bf: 16 B per (wave w, column block cb, k block kb,
+// piece, lane): element i = piece(W[32 kb + 8 (lane >> 4) + i][w (U/4) + 16 cb + (lane & 15)]); one dword = two elements
+__global__ void node_pack_bf16_kernel(const float* __restrict__ W, int K, int U, float* __restrict__ packed) {
+  const int ncb = U / 64, total = K * U * 3 / 2;   // dwords
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
+    const int d = i & 3, lane = (i >> 2) & 63;
+    int rest = i >> 8;
+    const int pc = rest % 3;
+    rest /= 3;
+    const int kb = rest % (K / 32);
+    rest /= (K / 32);
+    const int cb = rest % ncb, w = rest / ncb;
+    const int col = w * (U / 4) + 16 * cb + (lane & 15);
+    unsigned bits[2];
+    for (int e = 0; e < 2; ++e) {
+      const int k = 32 * kb + 8 * (lane >> 4) + 2 * d + e;
+      const float x = W[k * U + col];
+      const __bf16 p0 = static_cast<__bf16>(x);
+      const float r1 = x - static_cast<float>(p0);
+      const __bf16 p1 = static_cast<__bf16>(r1);
+      const float r2 = r1 - static_cast<float>(p1);
+      const __bf16 p2 = static_cast<__bf16>(r2);
+      const __bf16 pick = pc == 0 ? p0 : (pc == 1 ? p1 : p2);
+      bits[e] = static_cast<unsigned>(__builtin_bit_cast(unsigned short, pick));
+    }
+    packed[i] = __uint_as_float(bits[0] | (bits[1] << 16));
+  }
+}
+
 template <int MODE, int E>
 int launch_node(const NodeArgs& a, int flags, hipStream_t s, const char* what) {
   if constexpr (MODE == NODE_MID || MODE == NODE_LAST) {   // the energy + force pass: packed images only
     if (a.save_d2)
       return (flags & 1) ? launch_node_impl<MODE, E, true, true, true>(a, s, what)
                          : launch_node_impl<MODE, E, false, true, true>(a, s, what);
+  }
+  if constexpr (MODE != NODE_UPD) {   // flags bit 6 (with bit 1): mp_schnet_node_pack_bf16_f32 images, bf16-pipe GEMMs
+    if ((flags & 66) == 66)
+      return (flags & 1) ? launch_node_impl<MODE, E, true, true, false, true>(a, s, what)
+                         : launch_node_impl<MODE, E, false, true, false, true>(a, s, what);
   }
   if constexpr (MODE != NODE_UPD) {   // flags bit 1: the weight pointers are mp_schnet_node_pack_f32 images
     if (flags & 2)
@@ -473,6 +523,11 @@ int launch_node(const NodeArgs& a, int flags, hipStream_t s, const char* what) {
 template <int E>
 void launch_stage0(const NodeArgs& a, const mp_prep::EdgePrepArgs& p, int node_blocks, unsigned grid, int flags_arg,
                    hipStream_t s) {
+  if ((flags_arg & 66) == 66) {   // bf16-piece weight images
+    if (flags_arg & 1) schnet_stage0_kernel<E, true, true, true, true><<<grid, 256, 0, s>>>(a, p, node_blocks);
+    else schnet_stage0_kernel<E, false, true, true, true><<<grid, 256, 0, s>>>(a, p, node_blocks);
+    return;
+  }
   switch (flags_arg & 3) {
     case 0: schnet_stage0_kernel<E, false, true, false><<<grid, 256, 0, s>>>(a, p, node_blocks); break;
     case 1: schnet_stage0_kernel<E, true, true, false><<<grid, 256, 0, s>>>(a, p, node_blocks); break;
@@ -568,6 +623,14 @@ int mp_schnet_node_pack_f32(const float* W, int K, int U, float* packed, mpStrea
              "required (got %d x %d)", K, U);
   node_pack_kernel<<<64, 256, 0, mp::as_stream(stream)>>>(W, K, U, packed);
   return mp::check_launch("mp_schnet_node_pack_f32");
+}
+
+int mp_schnet_node_pack_bf16_f32(const float* W, int K, int U, float* packed, mpStream_t stream) {
+  MP_REQUIRE(W && packed, "mp_schnet_node_pack_bf16_f32: null pointer");
+  MP_REQUIRE(K >= 32 && K % 32 == 0 && U >= 64 && U % 64 == 0, "mp_schnet_node_pack_bf16_f32: K %% 32 == 0 and "
+             "U %% 64 == 0 required (got %d x %d)", K, U);
+  node_pack_bf16_kernel<<<64, 256, 0, mp::as_stream(stream)>>>(W, K, U, packed);
+  return mp::check_launch("mp_schnet_node_pack_bf16_f32");
 }
 
 int mp_schnet_node_residual_f32(const float* agg, int64_t N, const float* W2, const float* b2, const float* W3,

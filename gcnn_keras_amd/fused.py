@@ -10,6 +10,8 @@ Every buffer is allocated when a batch is bound; ``forward()`` only replays the 
 """
 import ctypes
 
+import os
+
 import numpy as np
 import torch
 
@@ -85,7 +87,10 @@ def pack_weights(p, depth, bins, out=None):
     if out is None:
         out = {"cfconv": [torch.empty(nfl, dtype=torch.float32, device="cuda") for _ in range(depth)],
                "node": {k: torch.empty(p[k].numel(), dtype=torch.float32, device="cuda")
-                        for k in node_weight_names(depth)}}
+                        for k in node_weight_names(depth)},
+               # the same matrices as three bf16 pieces per element (the forward's node kernels on the bf16 pipe)
+               "node_bf": {k: torch.empty(p[k].numel() * 3 // 2, dtype=torch.float32, device="cuda")
+                           for k in node_weight_names(depth)}}
     for i in range(depth):
         pre = "interaction%d/cfconv/" % i
         _ffi.call("mp_cfconv_pack_f32", _ffi.ptr(p[pre + "dense1/kernel"]), _ffi.ptr(p.get(pre + "dense1/bias")),
@@ -94,6 +99,9 @@ def pack_weights(p, depth, bins, out=None):
     for k, image in out["node"].items():
         _ffi.call("mp_schnet_node_pack_f32", _ffi.ptr(p[k]), int(p[k].shape[0]), int(p[k].shape[1]), _ffi.ptr(image),
                   _ffi.stream())
+    for k, image in out.get("node_bf", {}).items():
+        _ffi.call("mp_schnet_node_pack_bf16_f32", _ffi.ptr(p[k]), int(p[k].shape[0]), int(p[k].shape[1]),
+                  _ffi.ptr(image), _ffi.stream())
     torch.cuda.current_stream().synchronize()
     return out
 
@@ -126,6 +134,11 @@ class FusedSchnet:
         # filter-MLP weights of every block in the cfconv kernel's LDS image order (packed once per weight update)
         images = packed if packed is not None else pack_weights(self.p, depth, int(self.gauss["bins"]))
         self.packed, self.node_images = images["cfconv"], images["node"]
+        # flags bit 6: node-side GEMMs on the bf16 matrix pipe (exact FP32 emulation, csrc/mp_node_tile.h) from the
+        # bf16-piece images; MPENGINE_NODE_BF16=0 keeps the FP32 matrix instructions
+        if "node_bf" in images and os.environ.get("MPENGINE_NODE_BF16", "1") != "0":
+            self.node_images = images["node_bf"]
+            self.flags_arg |= 64
         self.stream = torch.cuda.Stream()
         self.graph = None
         self.num_launches = 1 + 2 * depth + 1
@@ -139,7 +152,7 @@ class FusedSchnet:
         (the only host synchronisation of a batch's life, on the current stream only)."""
         self._b, self.N, self.M, self.G = b, n, m, g
         i64 = 256 if b["z"].dtype == torch.int64 else 0      # flags bit 8: int64 node numbers (the fork's input dtype)
-        self.node_flags = (self.flags_arg & 3) | i64
+        self.node_flags = (self.flags_arg & (3 | 64)) | i64
         dev = "cuda"
         self.recv = torch.empty(max(m, 1), dtype=torch.int32, device=dev)
         self.send = torch.empty(max(m, 1), dtype=torch.int32, device=dev)

@@ -373,6 +373,11 @@ int mp_edge_geometry_bwd_f32(const float* g_d, const float* g_rij, int slices, c
  * per wave and lane, the registers of four consecutive k-steps as one float4, so a workgroup loads its weight slices
  * with 16-B instead of strided 4-B reads. */
 int mp_schnet_node_pack_f32(const float* W, int K, int U, float* packed /* K*U floats */, mpStream_t stream);
+/* The same slice order with every element as three bf16 pieces (hi + mid + lo = the FP32 value exactly): flags bit 6
+ * (value 64, together with bit 1) makes the node kernels of the FORWARD run their GEMMs on the bf16 matrix pipe as an exact
+ * FP32 emulation (six products per k block, FP32 accumulate: the error of the FP32 matrix instructions at 2.67x their
+ * rate).  K % 32 == 0; the image holds K*U*3/2 floats. */
+int mp_schnet_node_pack_bf16_f32(const float* W, int K, int U, float* packed /* K*U*3/2 floats */, mpStream_t stream);
 /* SchNetInteraction.call's node side alone (schnet_conv.py:162-164), out of place, for the layer API:
  * n_out = n_in + Dense(lin)(Dense(ssp)(agg)); agg is left untouched. */
 int mp_schnet_node_residual_f32(const float* agg, int64_t N, const float* W2, const float* b2, const float* W3,
