@@ -343,6 +343,42 @@ def test_fused_schnet_forward(num_graphs, seed, shuffle):
     assert _rel_err(lay.forward().cpu().numpy(), out1) <= 1e-5
 
 
+@pytest.mark.parametrize("case", ["wide_range", "cancellation"])
+def test_node_kernels_on_the_bf16_pipe_keep_the_fp32_error_budget(case, monkeypatch):
+    """The forward's node kernels run their GEMMs on the bf16 matrix pipe as an FP32 emulation (three bf16 pieces per
+    operand, six products: csrc/mp_node_tile.h).  Node-side weights chosen against the scheme - magnitudes over six orders,
+    rows that cancel - must leave the forward as close to the float64 twin as the FP32 matrix instructions do
+    (MPENGINE_NODE_BF16=0) and inside the float32 oracle's own distance from it."""
+    from gcnn_keras_amd.engine import SchnetForward
+    b = synth.qm9_like_batch(num_graphs=9, seed=17)
+    p = {k: (None if v is None else v.copy()) for k, v in synth.schnet_params(seed=11, random_bias=True).items()}
+    rng = np.random.default_rng(3)
+    for i in range(3):
+        for name in ("interaction%d/dense2/kernel" % i, "interaction%d/dense3/kernel" % i):
+            w = p[name]
+            if case == "wide_range":
+                w *= (10.0 ** rng.uniform(-4, 2, size=w.shape)).astype(np.float32) * np.float32(0.05)
+            else:
+                w[1::2] = -w[0::2] * (1.0 + 1e-4 * rng.standard_normal(w[0::2].shape)).astype(np.float32)
+    args = (ko.R(b["node_number"], b["node_splits"]), ko.R(b["node_coordinates"], b["node_splits"]),
+            ko.R(b["edge_indices"], b["edge_splits"]))
+    ref = ko.schnet_forward(p, *args, depth=3)
+    ref64 = ko.schnet_forward(ko.to_dtype(p, np.float64), args[0], ko.R(b["node_coordinates"].astype(np.float64),
+                                                                       b["node_splits"]), args[2], depth=3)
+    oracle_err = _rel_err(ref, ref64)
+    errs = {}
+    for bf in ("1", "0"):
+        monkeypatch.setenv("MPENGINE_NODE_BF16", bf)
+        fwd = SchnetForward(p, depth=3, mode="fused")
+        fwd.load_batch(b)
+        out = fwd.forward().cpu().numpy().copy()
+        fwd.check_flags()
+        errs[bf] = _rel_err(out, ref64)
+        assert errs[bf] <= max(4 * oracle_err, 2e-6), (case, bf, errs[bf], oracle_err)
+        assert _rel_err(out, ref) <= max(1e-5, 8 * oracle_err)
+    assert errs["1"] <= max(2 * errs["0"], 2e-6), errs
+
+
 def test_fused_schnet_empty_graphs_and_isolated_nodes():
     from gcnn_keras_amd.engine import SchnetForward
     b = synth.qm9_like_batch(num_graphs=5, seed=2)
