@@ -9,20 +9,21 @@
 // reads 4 B (distance) or 4B B (rbf) + 8 B of indices per edge and adds each node row once or twice).
 //
 // Roofline: 2(BF + F^2) + 2F = 38.1 kflop per edge at F=128, B=20 against <= 100 B of compulsory traffic:
-// MFMA-bound.  FP32 results throughout (the 1e-5 budget; there is no TF32 on gfx950): GEMM1 (K = B + 1) runs on
-// v_mfma_f32_32x32x2_f32; GEMM2 (K = 128, 85 % of the matrix work) runs on the BF16 matrix pipe as an exact FP32
-// emulation - every FP32 operand is split into three bf16 pieces (8 + 8 + 8 mantissa bits: hi = bf16(x),
+// MFMA-bound.  FP32 results throughout (the 1e-5 budget; there is no TF32 on gfx950), computed on the BF16 matrix pipe as
+// an exact FP32 emulation - every FP32 operand is split into three bf16 pieces (8 + 8 + 8 mantissa bits: hi = bf16(x),
 // mid = bf16(x - hi), lo = bf16(x - hi - mid), each difference exact in FP32), and the six leading cross products
 // (hi hi, hi mid, mid hi, mid mid, hi lo, lo hi) are accumulated in FP32 by v_mfma_f32_32x32x16_bf16; the three dropped
 // products are below 2^-24 of |a||b|, the rounding of an FP32 product itself.  Measured on a 32x128x128 tile against
 // float64 (scripts/probes/bf16x3_probe.hip): max error 2.55e-7 of the output scale, the FP32 MFMA chain 2.56e-7.
-// Six 32-cycle MFMAs replace eight 64-cycle ones per 16 k: 2.67x the FP32 matrix rate for the same result.
+// GEMM2 (K = 128, 85 % of the matrix work): six 32-cycle MFMAs replace eight 64-cycle ones per 16 k, 2.67x the FP32
+// matrix rate for the same result.  GEMM1 (K = B + 1): the same for the basis sizes with their own build (20, 25: the k
+// slots of both lane halves fill two k blocks); other sizes keep v_mfma_f32_32x32x2_f32.
 //
 // Structure (F = 128 fixed; wave64; one wave owns a tile of 32 consecutive edges of the receiver-sorted list):
-//  * W1 (+ its bias as an extra input row) and W2 live in LDS for the whole persistent workgroup.  W1 rows are stored
-//    [4*c + blk] so that one ds_read_b128 yields the A operands of all four 32-wide hidden blocks; W2 is stored
-//    naturally and lane c of GEMM2 owns the four output features 4c..4c+3 (one per accumulator block), again one
-//    ds_read_b128 per k step.
+//  * W1 (+ its bias as an extra input row) and W2 live in LDS for the whole persistent workgroup, as bf16-piece images
+//    in MFMA operand order (one ds_read_b128 per piece and step; staged by LDS-DMA); lane c of GEMM2 owns the four output
+//    features 4c..4c+3 (one per accumulator block).  Generic basis sizes: W1 as FP32 rows [4*c + blk], one ds_read_b128
+//    yields the A operands of all four 32-wide hidden blocks.
 //  * GEMM1 is computed TRANSPOSED, hT[f][e] = sum_b W1[b][f] rbf[e][b]: its accumulator then has the edge on the
 //    lane and the feature in the register, which is exactly the A-operand layout of GEMM2 (edge rows, k = feature)
 //    - the 128x32 hidden tile goes from one MFMA chain to the next in registers, no LDS round trip, no shuffles.
@@ -40,10 +41,10 @@
 //    128-B line (device-scope atomics are paid per line).  A node whose edges span two tiles receives two adds onto a
 //    zero row, so the result is order independent (a + b == b + a); only receivers spanning three or more tiles
 //    (in-degree > 32) can differ in the last bit between runs.
-//  * FP32 MFMA and FP32 VALU share the SIMD's FP32 lanes on gfx950 (scripts/probes/mfma_probe.hip: a VALU instruction
-//    between two MFMAs of the same wave adds its full issue time, only scalar / LDS / memory instructions overlap), so
-//    with one wave per SIMD the kernel's time is 64 cycles per MFMA PLUS ~5 cycles per vector instruction: the
-//    non-matrix phases are written for instruction count (packed FP32, scalar control, 6-instruction softplus).
+//  * A bf16 MFMA holds the SIMD's vector issue for 8 of its 32 cycles: the vector work between the GEMMs (softplus,
+//    operand splits) is cut into tasks of <= 24 issue cycles and pinned to MFMA slots (see PIPE below); FP32 MFMAs (the
+//    generic builds' GEMM1) block the vector lanes entirely (scripts/probes/mfma_probe.hip), so the phases outside the
+//    matrix work are written for instruction count (packed FP32, scalar control, 6-instruction softplus).
 //  * The output buffer must be zero on entry (unconnected nodes keep 0 = the has_unconnected pad of
 //    kgcnn/layers/pooling.py:74-76).
 #include <mutex>
