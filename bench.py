@@ -239,10 +239,10 @@ def run_config2(args, d):
     latency_ms = (time.perf_counter() - t1) / 100 * 1e3
     roof = fwd.roofline(HBM_PEAK_GBS, FP32_MFMA_PEAK_TF)  # dominant kernel, timed with HIP events on its stream
     roof.update(pmc_traffic(roof.get("kernel", ""), n_graphs))
-    roof["measured"] = ("HIP events on the kernel's stream around back-to-back launches of the kernel alone on the GPU, "
-                        "after the timed region; rocprofv3 --kernel-trace --stats of `bench.py --in-flight 1` "
-                        "(profiles/) gives the same average; with batches in flight kernels of different batches share "
-                        "CUs and their individual durations stretch")
+    roof["measured"] = ("HIP events on the kernel's stream around back-to-back launches of the kernel alone on the GPU "
+                        "(50 launches per HIP-graph replay, so that the host's call rate is not what is timed), after "
+                        "the timed region; rocprofv3 --kernel-trace --stats of `bench.py --in-flight 1` (profiles/) "
+                        "gives the same average for the kernel inside the forward")
     if d.rank != 0:
         return None
     ms_per_step = elapsed / args.steps * 1e3

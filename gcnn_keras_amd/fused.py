@@ -378,8 +378,23 @@ class FusedSchnet:
         from .engine import _HipTimer
         scratch = torch.zeros_like(self.agg)
         bins = int(self.gauss["bins"])
+        # `iters` back-to-back launches captured in a HIP graph and replayed between two events: issued one by one through
+        # ctypes the launches arrive every ~10-11 us - the Python call rate, not the kernel (rocprofv3's 10.0 us average
+        # of the same kernel inside the forward is the cross-check, profiles/r02_fused_config2_kernel_stats.csv)
         with torch.cuda.stream(self.stream):
-            ms = _HipTimer().time_ms(lambda: self._cfconv(0, scratch), iters)
+            self._cfconv(0, scratch)
+            torch.cuda.synchronize()
+            _ffi.call("mp_graph_begin", _ffi.stream())
+            exe = ctypes.c_void_p()
+            try:
+                for _ in range(iters):
+                    self._cfconv(0, scratch)
+            finally:
+                _ffi.call("mp_graph_end", _ffi.stream(), ctypes.byref(exe))
+            try:
+                ms = _HipTimer().time_ms(lambda: _ffi.call("mp_graph_launch", exe, _ffi.stream()), 4) / iters
+            finally:
+                _ffi.call("mp_graph_destroy", exe)
         torch.cuda.synchronize()
         flops = float(self.M) * (2.0 * (bins * 128 + 128 * 128) + 2.0 * 128)
         # algorithmic bytes of one launch: distance + ids per edge, sender rows once, output rows once
