@@ -132,6 +132,7 @@ _SIGNATURES = {
     "mp_host_alloc": [c_size_t, c_int, P],
     "mp_host_free": [P, c_int],
     "mp_memcpy_h2d_async": [P, P, c_size_t, P],
+    "mp_gcn_tile_f32": [P, P],
 }
 _RESTYPES = {"mp_last_error": c_char_p}
 
@@ -159,6 +160,20 @@ class SchnetForceDesc(ctypes.Structure):
                 + [(name, c_void_p) for name in ("Wl0T", "Wl1T", "seg0", "perm0", "seg1", "perm1", "ptr0", "ptr1",
                                                  "g_n", "g_agg", "g_x", "g_d", "force")]
                 + [("force_scale", c_float)])
+
+
+class GcnLayerDesc(ctypes.Structure):
+    """``mp_gcn_layer`` of include/mpengine.h."""
+    _fields_ = [("W", c_void_p), ("b", c_void_p), ("units", ctypes.c_int32), ("act", ctypes.c_int32), ("alpha", c_float)]
+
+
+class GcnTileDesc(ctypes.Structure):
+    """``mp_gcn_tile_desc`` of include/mpengine.h (field for field)."""
+    _fields_ = [("N", c_int64), ("x", c_void_p), ("K", c_int64), ("W_in", c_void_p), ("b_in", c_void_p),
+                ("h", c_void_p), ("ptr", c_void_p), ("perm", c_void_p), ("send", c_void_p), ("weight", c_void_p),
+                ("M", c_int64), ("agg_act", ctypes.c_int32), ("agg_alpha", c_float),
+                ("units_in", ctypes.c_int32), ("n_layers", ctypes.c_int32), ("layer", GcnLayerDesc * 3),
+                ("softmax_last", ctypes.c_int32), ("out", c_void_p)]
 
 
 _lib = None

@@ -9,8 +9,8 @@
 Every buffer is allocated when a batch is bound; ``forward()`` only replays the captured graph.
 """
 import ctypes
-
 import os
+import sys
 
 import numpy as np
 import torch
@@ -141,6 +141,7 @@ class FusedSchnet:
             self.flags_arg |= 64
         self.stream = torch.cuda.Stream()
         self.graph = None
+        self._ring, self._ring_next = [], 0
         self.num_launches = 1 + 2 * depth + 1
         self._b = None
 
@@ -186,7 +187,8 @@ class FusedSchnet:
         while rows > 0 and splits[rows] == splits[rows - 1]:
             rows -= 1
         self.out_rows = rows  # tf.math.segment_sum drops trailing empty graphs (kgcnn/layers/pooling.py:215-219)
-        self.graph = None
+        self._drop_graphs()
+        self._ring, self._ring_next = [], 0
         self._desc = self._desc_ref = None
 
     def _prepare(self):
@@ -203,7 +205,7 @@ class FusedSchnet:
                   _ffi.ptr(recv), _ffi.ptr(self.send), _ffi.ptr(self.perm), self.M, self.flags_arg, _ffi.ptr(out),
                   _ffi.stream())
 
-    def _launch_all(self):
+    def _launch_all(self, out=None):
         # One linear chain on one stream.  (A two-branch graph - node_in beside edge_prepare - was measured 9 % SLOWER
         # at config 2: the fork/join costs more than the ~5 us of overlap it buys.)
         p, b, w = self.p, self._b, self.node_images
@@ -240,7 +242,7 @@ class FusedSchnet:
                           _ffi.ptr(p.get("last_mlp/1/bias")), _ffi.ptr(self.h), self.node_flags, _ffi.stream())
         wo0, bo0, wo1, bo1 = self._head()
         _ffi.call("mp_schnet_readout_f32", _ffi.ptr(self.h), _ffi.ptr(b["ns"]), self.G, _ffi.ptr(wo0), _ffi.ptr(bo0),
-                  _ffi.ptr(wo1), _ffi.ptr(bo1), _ffi.ptr(self.out), _ffi.stream())
+                  _ffi.ptr(wo1), _ffi.ptr(bo1), _ffi.ptr(self.out if out is None else out), _ffi.stream())
 
     def _head(self):
         p = self.p
@@ -250,18 +252,68 @@ class FusedSchnet:
                 p.get("output_mlp/1/bias"))
 
     # ------------------------------------------------------------------------------------------------ current stream
-    def _capture(self):
-        """Capture the eight launches on this slot's private stream (a captured graph can be launched on any stream)."""
+    def _capture(self, out=None):
+        """Capture the eight launches on this slot's private stream (a captured graph can be launched on any stream);
+        ``out``: the result buffer the readout of THIS graph writes (default: the slot's static buffer)."""
         with torch.cuda.stream(self.stream):
-            self._launch_all()  # warm-up outside capture (lazy module load, function attributes)
+            self._launch_all(out)  # warm-up outside capture (lazy module load, function attributes)
             self.stream.synchronize()
             _ffi.call("mp_graph_begin", _ffi.stream())
             try:
-                self._launch_all()
+                self._launch_all(out)
             finally:
                 exe = ctypes.c_void_p()
                 _ffi.call("mp_graph_end", _ffi.stream(), ctypes.byref(exe))
-        self.graph = exe
+        if out is None:
+            self.graph = exe
+        return exe
+
+    # ------------------------------------------------------------------------------------------------ result ring
+    # A Keras model call returns a NEW tensor.  Copying the slot's static (G,1) buffer into a fresh allocation costs a
+    # launch of its own per forward (4.3 us of 64 at config 2).  Instead the slot keeps a few result buffers, each with
+    # its own captured graph (same kernels, same work buffers - only the readout's destination differs), and hands out
+    # a buffer only while nobody else holds it or a view of it (storage use count and Python reference count back at
+    # their idle values): to the caller that is indistinguishable from a fresh tensor, and a result somebody still
+    # holds is never written again.  No idle buffer -> the static buffer and a copy, as before.
+    RING = 3
+
+    @staticmethod
+    def _holders(t):
+        return torch._C._storage_Use_Count(t.untyped_storage()._cdata), sys.getrefcount(t)
+
+    def run_graph_fresh(self):
+        """Replay the forward on torch's current stream into a result buffer nobody else references; returns that
+        ``(G', 1)`` tensor, or ``None`` when every ring buffer is still held by a caller."""
+        ring = self._ring
+        entry = None
+        for k in range(len(ring)):
+            cand = ring[(self._ring_next + k) % len(ring)]
+            if self._holders(cand[0]) == cand[2]:
+                entry = cand
+                self._ring_next = (self._ring_next + k + 1) % len(ring)
+                break
+        if entry is None:
+            if len(ring) >= self.RING:
+                return None
+            entry = [torch.zeros((self.G, 1), dtype=torch.float32, device="cuda"), None, None]
+            ring.append(entry)
+            entry[2] = self._holders(entry[0])
+            self._ring_next = 0
+        if entry[1] is None:
+            torch.cuda.current_stream().synchronize()
+            entry[1] = self._capture(entry[0])
+        _ffi.call("mp_graph_launch", entry[1], _ffi.stream())
+        return entry[0] if self.out_rows == self.G else entry[0][:self.out_rows]
+
+    def _drop_graphs(self):
+        for exe in [getattr(self, "graph", None)] + [e[1] for e in getattr(self, "_ring", [])]:
+            if exe is not None:
+                try:
+                    _ffi.call("mp_graph_destroy", exe)
+                except Exception:
+                    pass
+        self.graph = None
+        self._ring = []
 
     def run_current(self, how="graph"):
         """One forward of the bound batch on torch's CURRENT stream (ordinary stream semantics for the caller):
@@ -423,8 +475,7 @@ class FusedSchnet:
 
     def __del__(self):
         try:
-            if self.graph is not None:
-                _ffi.call("mp_graph_destroy", self.graph)
+            self._drop_graphs()
         except Exception:
             pass
 
@@ -530,8 +581,12 @@ class SchnetFusedRoute:
         how = self.mode
         if how == "auto":
             how = "direct" if slot.calls == 1 else "graph"
-        out = slot.run_current(how)
         self.last = how
+        if how == "graph" and self.copy_output:
+            out = slot.run_graph_fresh()   # a result buffer nobody else holds: no copy launch
+            if out is not None:
+                return out
+        out = slot.run_current(how)
         return out.clone() if self.copy_output else out
 
     def energy_force(self, inputs):

@@ -5,6 +5,7 @@ from ..layers.mlp import MLP, GraphMLP
 from ..layers.modules import Dense, OptionalInputEmbedding
 from ..layers.pooling import PoolingNodes
 from ..model.utils import Model, update_model_kwargs
+from .. import fused_gcn as _fused
 
 __model_version__ = "2022.11.25"
 
@@ -44,7 +45,14 @@ def make_model(inputs: list = None, input_embedding: dict = None, depth: int = N
     cast = ChangeTensorType(input_tensor_type="ragged", output_tensor_type="tensor") \
         if (output_embedding == "node" and output_to_tensor) else None
 
-    def forward(model_inputs, **kwargs):
+    def forward(model_inputs, fused=None, **kwargs):
+        # Fused route (csrc/mp_gcn.hip: input GEMM + depth x (aggregate + next Dense / output MLP) = 1 + depth launches,
+        # graph-replayed for a re-bound input set) whenever configuration and inputs fit it and no gradient is requested;
+        # ``fused=False`` forces the layer sequence below, ``fused=True`` insists on the kernels.
+        if route is not None and fused is not False and route.accepts(model_inputs):
+            return route(model_inputs)
+        if fused is True:
+            raise ValueError("this GCN configuration / these inputs do not fit the fused kernels")
         node_input, edge_input, edi = model_inputs
         n = embed_n(node_input)
         ed = embed_e(edge_input)
@@ -64,8 +72,15 @@ def make_model(inputs: list = None, input_embedding: dict = None, depth: int = N
     for lay in gcns:
         lay.ensure_built([(None, None, units), (None, None, 1), (None, None, 2)])
     out_mlp.ensure_built((None, units) if output_embedding == "graph" else (None, None, units))
+    route = None
+    if _fused.supports({"inputs": inputs, "gcn_args": gcn_args, "depth": depth, "output_embedding": output_embedding,
+                        "output_mlp": output_mlp}):
+        route = _fused.GcnFusedRoute(dense0, gcns, out_mlp, cast)
     model = Model(name, forward, [embed_n, embed_e, dense0] + gcns + [out_mlp], config={"depth": depth,
                                                                                          "gcn_args": gcn_args})
     model.__kgcnn_model_version__ = __model_version__
-    model.auto_graph = True   # re-bound inputs replay the whole layer sequence from one HIP graph (model/utils.py)
+    model.fused = route       # None: this configuration always runs the layer sequence
+    # the layer sequence (graph output, other widths, gradients) is replayed from one HIP graph for re-bound inputs
+    # (model/utils.py); a call the fused route takes manages its own graphs
+    model.auto_graph = route is None
     return model

@@ -462,6 +462,36 @@ typedef struct mp_schnet_forward_desc {
 } mp_schnet_forward_desc;
 int mp_schnet_forward_launch(const mp_schnet_forward_desc* desc_host, mpStream_t stream);
 
+/* ---------------------------------------------------------------- fused GCN forward -------------------------- */
+/* The forward of kgcnn.literature.GCN.make_model (kgcnn/literature/GCN.py:95-109) in 1 + depth launches on 16-node
+ * tiles, each launch = one producer of the tile followed by up to three Keras Dense layers on it:
+ *   input mode (x != NULL):      t = x (N,K) W_in (K,units_in) + b_in           GCN.py:97  Dense(units, linear)
+ *   aggregate mode (x == NULL):  t_i = agg_act( sum_{e: recv(e) = i} weight[e] * h[send[e]] )
+ *                                kgcnn/layers/conv/gcn_conv.py:87-90: GatherNodesOutgoing, PoolingWeightedLocalEdges
+ *                                (sum, normalize_by_weights=False), Activation; receivers through the CSR `ptr` (N+1)
+ *                                over the receiver-sorted edge order, `perm` (nullable) = position -> edge for a list
+ *                                that is not sorted (tf.argsort(stable=True), kgcnn/layers/pooling.py:66)
+ *   then  t <- act_l(t W_l + b_l)  for l < n_layers (gcn_conv.py:86 lay_dense of the next layer, or GraphMLP,
+ *   GCN.py:107), softmax_last: Keras softmax over the last layer's units.  out (N, units of the last layer; units_in
+ *   if n_layers == 0).  units_in in {32, 64, 128}, layer widths 1..128.  Sums run in a fixed order: deterministic. */
+typedef struct mp_gcn_layer {
+  const float* W;   /* (K_l, units) Keras kernel */
+  const float* b;   /* (units) or NULL */
+  int32_t units, act;
+  float alpha;
+} mp_gcn_layer;
+typedef struct mp_gcn_tile_desc {
+  int64_t N;
+  const float* x; int64_t K; const float* W_in; const float* b_in;                      /* input mode */
+  const float* h; const int32_t* ptr; const int32_t* perm; const int32_t* send;         /* aggregate mode */
+  const float* weight; int64_t M; int32_t agg_act; float agg_alpha;
+  int32_t units_in, n_layers;
+  mp_gcn_layer layer[3];
+  int32_t softmax_last;
+  float* out;
+} mp_gcn_tile_desc;
+int mp_gcn_tile_f32(const mp_gcn_tile_desc* desc_host, mpStream_t stream);
+
 /* ---------------------------------------------------------------- Dense chains on 16-row tiles ------------ */
 /* One or two Keras Dense layers back to back (kgcnn/layers/modules.py:74-87; PAiNNconv / PAiNNUpdate's
  * Dense(units, act) -> Dense(3 units), kgcnn/layers/conv/painn_conv.py:60-62,187-189, and their reverse forms) in one

@@ -3,10 +3,12 @@ F = 1433 -> 64, depth 3, head [64, 32, 7] softmax) on one MI355X.
 
     python scripts/bench_gcn.py
 
-Prints ONE JSON line: latency of ``GCN.make_model(...)(inputs)`` eager and replayed from the model's own HIP graph
-(``auto_graph``), and the two kernels that carry the data - the first Dense (reads the (2708,1433) feature matrix:
-15.5 MB, HBM-bound; split-K over workgroups) and the fused gather x weight -> segment-sum -> ReLU aggregate (125 B/edge)
-- timed alone with HIP events, each against the roofline that bounds it.  A parity configuration, not the headline line."""
+Prints ONE JSON line: latency of ``GCN.make_model(...)(inputs)`` - the fused route (csrc/mp_gcn.hip: 1 + depth tile
+launches replayed from a HIP graph) and the layer sequence (``fused=False``, one engine call per Keras layer) - and the
+kernels that carry the data, timed alone with HIP events, each against the roofline that bounds it: the fused route's
+input launch (reads the (2708,1433) feature matrix: 15.5 MB) and layer launch (aggregate + Dense), and the layer path's
+first Dense (split-K) and gather x weight -> segment-sum -> ReLU aggregate (125 B/edge).  A parity configuration, not
+the headline line."""
 import json
 import os
 import sys
@@ -47,16 +49,26 @@ def main():
                            depth=3, output_embedding="node",
                            output_mlp={"use_bias": [True, True, False], "units": [64, 32, 7],
                                        "activation": ["relu", "relu", "softmax"]})
-    model.auto_graph = False
-    t_eager = timeit(lambda: model(ins), 50)
-    model.auto_graph = True
+    t_layers = timeit(lambda: model(ins, fused=False), 50)
     model(ins), model(ins)
-    assert model.last_route == "graph"
+    assert model.fused is not None and model.fused.last == "graph"
     t_graph = timeit(lambda: model(ins), 500)
     out = {"workload": "BASELINE config 5: GCN.make_model on one Cora-shaped graph, N=%d, M=%d (incl. self loops), F=%d" %
-                       (n, m, f), "nodes": n, "edges": m, "forward_ms_eager": t_eager * 1e3,
-           "forward_ms_graph_replay": t_graph * 1e3, "edges_per_s": m / t_graph}
+                       (n, m, f), "nodes": n, "edges": m, "forward_ms_layer_path_eager": t_layers * 1e3,
+           "forward_ms_fused_graph_replay": t_graph * 1e3, "edges_per_s": m / t_graph}
     timer = _HipTimer()
+    # the fused route's launches alone (descriptors of the bound slot)
+    import ctypes
+    slot = model.fused.slot_of(ins)
+    descs = slot._descs(torch.empty((n, 7), device="cuda"))
+    for name, d, alg, flops in (
+            ("gcn_tile_kernel<input> X W0 + b0, then gcn0 Dense", descs[0], 4 * (n * f + f * 64 + n * 64),
+             2.0 * n * f * 64 + 2.0 * n * 64 * 64),
+            ("gcn_tile_kernel<aggregate> sum_e w_e h[send] -> relu -> next Dense", descs[1], 20 * m + 8 * n * 64,
+             2.0 * m * 64 + 2.0 * n * 64 * 64)):
+        ms = timer.time_ms(lambda: _ffi.call("mp_gcn_tile_f32", ctypes.byref(d), _ffi.stream()), 50)
+        out[name] = {"avg_launch_us": ms * 1e3, "algorithmic_bytes": alg, "gbs": alg / (ms * 1e-3) / 1e9,
+                     "bound": "hbm", "frac": alg / (ms * 1e-3) / 1e9 / HBM_PEAK, "tflops": flops / (ms * 1e-3) / 1e12}
     x = ins[0].values
     w = torch.randn(f, 64, device="cuda") * 0.05
     b = torch.zeros(64, device="cuda")

@@ -406,10 +406,11 @@ def test_forwards_in_flight_are_independent_and_identical():
     p = synth.schnet_params(seed=7, random_bias=True)
     multi = SchnetForward(p, depth=3, mode="fused", in_flight=3)
     multi.load_batch(b)
+    last = {}
     for i in range(30):                      # slots overlap on the GPU
-        multi.replay(i)
+        last[i % 3] = multi.replay(i)
     torch.cuda.synchronize()
-    outs = [multi._slots[k].out.clone() for k in range(3)]
+    outs = [last[k].clone() for k in range(3)]
     assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2])
     lone = multi.forward(0).clone()
     torch.cuda.synchronize()
@@ -457,10 +458,11 @@ def test_slots_with_unsorted_receivers_and_direct_launch_fallback():
     fwd = SchnetForward(p, depth=3, mode="fused", in_flight=2)
     fwd.load_batch(b)
     assert not fwd._slots[0].sorted
+    last = {}
     for i in range(6):
-        fwd.replay(i)
+        last[i % 2] = fwd.replay(i)
     torch.cuda.synchronize()
-    a, c = fwd._slots[0].out.clone(), fwd._slots[1].out.clone()
+    a, c = last[0].clone(), last[1].clone()
     assert torch.equal(a, c)
     with torch.cuda.stream(fwd._slots[0].stream):
         d = fwd._slots[0].launch_direct().clone()
@@ -470,3 +472,45 @@ def test_slots_with_unsorted_receivers_and_direct_launch_fallback():
                             ko.R(b["edge_indices"], b["edge_splits"]), depth=3)
     assert _rel_err(a.cpu().numpy(), ref) <= 1e-5
     fwd.check_flags()
+
+
+def test_model_call_returns_a_tensor_nobody_else_holds():
+    """``model(inputs)`` on a re-bound batch replays a graph whose readout writes into one of the slot's result buffers
+    (no copy launch); a buffer is handed out only while no caller holds it or a view of it, so results behave like the
+    fresh tensors a Keras call returns: held results are never written again, dropped ones are recycled."""
+    from gcnn_keras_amd import _ffi
+    from gcnn_keras_amd.literature import Schnet
+    from gcnn_keras_amd.ragged import RaggedTensor
+    b = synth.qm9_like_batch(num_graphs=9, seed=5)
+    p = synth.schnet_params(seed=7, random_bias=True)
+    model = Schnet.make_model(depth=3)
+    model.set_weights(list(p.values()))
+    xyz = RaggedTensor.from_numpy(b["node_coordinates"], b["node_splits"])
+    inputs = [RaggedTensor.from_numpy(b["node_number"], b["node_splits"]), xyz,
+              RaggedTensor.from_numpy(b["edge_indices"], b["edge_splits"])]
+    first = model(inputs)                       # bind + direct launch (copy of the static buffer)
+    held = [model(inputs) for _ in range(5)]    # more results held than the ring has buffers
+    torch.cuda.synchronize()
+    ptrs = {t.data_ptr() for t in held} | {first.data_ptr()}
+    assert len(ptrs) == 6                       # all distinct storages
+    want = first.clone()
+    assert all(torch.equal(t, want) for t in held)
+    view = held[0][:3]                          # a view keeps its buffer out of circulation too
+    base_ptr = held[0].data_ptr()
+    del held
+    xyz.values.mul_(1.05)                       # new coordinates in the bound tensor: later calls give other numbers
+    later = [model(inputs) for _ in range(4)]
+    torch.cuda.synchronize()
+    assert all(t.data_ptr() != base_ptr for t in later)
+    assert torch.equal(view, want[:3]) and torch.equal(first, want)
+    assert not torch.equal(later[0], want) and all(torch.equal(t, later[0]) for t in later)
+    ref = ko.schnet_forward(p, ko.R(b["node_number"], b["node_splits"]),
+                            ko.R(b["node_coordinates"] * np.float32(1.05), b["node_splits"]),
+                            ko.R(b["edge_indices"], b["edge_splits"]), depth=3)
+    assert _rel_err(later[0].cpu().numpy(), ref) <= 1e-5
+    # a loop that drops its results runs on the ring alone: one graph launch per call, the buffers come round again
+    del later, view
+    before = _ffi.launch_count()
+    seen = {model(inputs).data_ptr() for _ in range(8)}
+    assert _ffi.launch_count() - before == 8 and len(seen) <= 3
+    assert model.fused.last == "graph"

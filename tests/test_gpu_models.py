@@ -415,3 +415,67 @@ def test_gin_builder_forward():
     assert np.max(np.abs(out - ref)) <= 2e-5
     with pytest.raises(NotImplementedError):
         GIN.make_model(gin_mlp={"use_normalization": True})
+
+
+@pytest.mark.parametrize("units,mlp_units,mlp_act,sort_edges", [(64, [64, 32, 7], ["relu", "relu", "softmax"], True),
+                                                               (32, [16, 5], ["kgcnn>leaky_relu", "linear"], False),
+                                                               (128, [100], ["softmax"], True)])
+def test_gcn_fused_route_equals_layer_sequence(units, mlp_units, mlp_act, sort_edges):
+    """``GCN.make_model(...)(inputs)`` takes the tile kernels of csrc/mp_gcn.hip (1 + depth launches, graph-replayed for
+    a re-bound input set); ``fused=False`` runs the reference's layer sequence on the same weights.  Several graphs of
+    different sizes, a hub receiver (in-degree > 100: its edges are shared by all thread groups of a tile), an isolated
+    node, a feature count that is not a multiple of 16, optionally an edge list that is not receiver-sorted."""
+    from gcnn_keras_amd import _ffi
+    from gcnn_keras_amd.literature import GCN
+    rng = np.random.default_rng(units)
+    sizes = [37, 150, 16, 1, 60]
+    feats = 45
+    attrs, wts, idxs, ns, es = [], [], [], [0], [0]
+    for g, n in enumerate(sizes):
+        m = 0 if n == 1 else 4 * n
+        i = rng.integers(0, n, size=m)
+        j = rng.integers(0, n, size=m)
+        if g == 1:
+            i[:120] = 7                       # a hub
+            i[i == 9] = 8                     # and a node nobody sends to
+        if sort_edges:
+            order = np.lexsort((j, i))
+            i, j = i[order], j[order]
+        attrs.append(rng.normal(size=(n, feats)).astype(np.float32))
+        wts.append(rng.uniform(0.05, 1.0, size=(m, 1)).astype(np.float32))
+        idxs.append(np.stack([i, j], axis=1).astype(np.int64).reshape(m, 2))
+        ns.append(ns[-1] + n)
+        es.append(es[-1] + m)
+    attrs, wts, idxs = np.concatenate(attrs), np.concatenate(wts), np.concatenate(idxs)
+    ns, es = np.asarray(ns, np.int64), np.asarray(es, np.int64)
+    p = synth.gcn_params(seed=3, depth=2, in_features=feats, units=units, out_units=tuple(mlp_units), random_bias=True)
+    model = GCN.make_model(
+        inputs=[{"shape": (None, feats), "name": "node_attributes", "dtype": "float32", "ragged": True},
+                {"shape": (None, 1), "name": "edge_weights", "dtype": "float32", "ragged": True},
+                {"shape": (None, 2), "name": "edge_indices", "dtype": "int64", "ragged": True}],
+        gcn_args={"units": units, "use_bias": True, "activation": "relu", "pooling_method": "sum"},
+        depth=2, output_embedding="node", output_to_tensor=False,
+        output_mlp={"use_bias": True, "units": mlp_units, "activation": mlp_act})
+    model.set_weights(list(p.values()))
+    assert model.fused is not None
+    ins = [_dev(attrs, ns), _dev(wts, es), _dev(idxs, es)]
+    first = model(ins)                       # direct launches
+    assert model.fused.last == "eager"
+    second = model(ins)                      # captured on this call ...
+    before = _ffi.launch_count()
+    third = model(ins)                       # ... a second result buffer is captured while `second` is held ...
+    del third
+    before = _ffi.launch_count()
+    third = model(ins)                       # ... and from here on a call is a single graph launch
+    assert model.fused.last == "graph" and _ffi.launch_count() - before == 1
+    layers = model(ins, fused=False).values.cpu().numpy()
+    torch.cuda.synchronize()
+    got = first.values.cpu().numpy()
+    assert np.array_equal(got, second.values.cpu().numpy()) and np.array_equal(got, third.values.cpu().numpy())
+    assert second.values.data_ptr() != third.values.data_ptr()
+
+    def oracle(dtype):
+        return ko.gcn_forward(ko.to_dtype(p, dtype), ko.R(attrs.astype(dtype), ns), ko.R(wts.astype(dtype), es),
+                              ko.R(idxs, es), depth=2, output_mlp_act=tuple(mlp_act)).values
+    _check(got, oracle(np.float32), oracle(np.float64))
+    _check(layers, oracle(np.float32), oracle(np.float64))
