@@ -22,6 +22,8 @@
 //    partial rows in LDS, the partials of a receiver are added in chunk order: deterministic, no atomics.
 //  * the Dense layers that follow run on the tile in LDS (A operand) with the weights read from L2 (B operand: at most
 //    128 x 128 floats per layer), 16 output columns per wave and step.
+#include <type_traits>
+
 #include "mp_common.h"
 
 namespace {
@@ -137,7 +139,7 @@ __global__ __launch_bounds__(256) void gcn_tile_kernel(GcnArgs a) {
     const int64_t full = K / 16;                 // 16-k blocks that need no bounds checks
     // block kb: lane (cc, g) supplies X[row][16 kb + 4 g + i] for MFMA i, and W[16 kb + 4 g + i][64 q + 4 cc + c]
     auto load_a = [&](int64_t kb, f4u& av) {
-      av = row_ok ? *reinterpret_cast<const f4u*>(xrow + 16 * kb + 4 * g) : f4u{0.f, 0.f, 0.f, 0.f};
+      av = *reinterpret_cast<const f4u*>(xrow + 16 * kb + 4 * g);   // rows past N read row 0; their results are dropped
     };
     auto load_b = [&](int64_t kb, f4u (&bv)[NCG][4]) {
       const int64_t k0 = 16 * kb + 4 * g;
@@ -146,7 +148,12 @@ __global__ __launch_bounds__(256) void gcn_tile_kernel(GcnArgs a) {
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
           const int col = 64 * q + 4 * cc;
-          bv[q][i] = col < UA ? *reinterpret_cast<const f4u*>(a.W_in + (k0 + i) * UA + col) : f4u{0.f, 0.f, 0.f, 0.f};
+          if constexpr (64 * NCG == UA) {
+            bv[q][i] = *reinterpret_cast<const f4u*>(a.W_in + (k0 + i) * UA + col);
+          } else {   // UA = 32: lanes 8..15 have no column
+            bv[q][i] = *reinterpret_cast<const f4u*>(a.W_in + (k0 + i) * UA + (col < UA ? col : 0));
+            if (col >= UA) bv[q][i] = f4u{0.f, 0.f, 0.f, 0.f};
+          }
         }
     };
     auto mma_block = [&](const f4u& av, const f4u (&bv)[NCG][4]) {
@@ -162,21 +169,24 @@ __global__ __launch_bounds__(256) void gcn_tile_kernel(GcnArgs a) {
       // wave w owns blocks w, w + 4, ...  The A rows come from HBM (latency 1-2 us against 0.25 us of MFMA work per
       // block): seven blocks of A are in flight ahead of the one being multiplied (4 registers each); the W rows are L2
       // hits and 16 * NCG registers per block: three ahead.
+      // Every load of the loop is unconditional (steps past the wave's last block re-read that block, unused): with a
+      // load inside a conditional the compiler's wait-count bookkeeping falls back to s_waitcnt vmcnt(0) right behind
+      // the prefetch - one full memory round trip per block (seen in the ISA; 15.4 us per launch).  Only the MFMAs of a
+      // step are skipped, by a wave-uniform branch.
       const int64_t nsteps = wave < full ? (full - wave + 3) / 4 : 0;
-      f4u av[8], bv[4][NCG][4];
+      if (nsteps > 0) {
+        auto blk = [&](int64_t step) { return wave + 4 * (step < nsteps ? step : nsteps - 1); };
+        f4u av[8], bv[4][NCG][4];
 #pragma unroll
-      for (int u = 0; u < 7; ++u)
-        if (u < nsteps) load_a(wave + 4 * u, av[u]);
+        for (int u = 0; u < 7; ++u) load_a(blk(u), av[u]);
 #pragma unroll
-      for (int u = 0; u < 3; ++u)
-        if (u < nsteps) load_b(wave + 4 * u, bv[u]);
-      for (int64_t t = 0; t < nsteps; t += 8) {
+        for (int u = 0; u < 3; ++u) load_b(blk(u), bv[u]);
+        for (int64_t t = 0; t < nsteps; t += 8) {
 #pragma unroll
-        for (int u = 0; u < 8; ++u) {
-          if (t + u < nsteps) {
-            if (t + u + 7 < nsteps) load_a(wave + 4 * (t + u + 7), av[(u + 7) & 7]);
-            if (t + u + 3 < nsteps) load_b(wave + 4 * (t + u + 3), bv[(u + 3) & 3]);
-            mma_block(av[u], bv[u & 3]);
+          for (int u = 0; u < 8; ++u) {
+            load_a(blk(t + u + 7), av[(u + 7) & 7]);
+            load_b(blk(t + u + 3), bv[(u + 3) & 3]);
+            if (t + u < nsteps) mma_block(av[u], bv[u & 3]);
           }
         }
       }
@@ -287,22 +297,23 @@ __global__ __launch_bounds__(256) void gcn_tile_kernel(GcnArgs a) {
         int slot = gbase[grp];
         int cur = -1;
         float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
-        for (int e0 = c_lo; e0 < c_hi; e0 += 8) {
-          int src[8], nid[8];
-          float wv[8];
-          float4 v[8];
+        auto round = [&](int e0, auto rows_tag) {
+          constexpr int R = decltype(rows_tag)::value;
+          int src[R], nid[R];
+          float wv[R];
+          float4 v[R];
 #pragma unroll
-          for (int u = 0; u < 8; ++u) {
+          for (int u = 0; u < R; ++u) {
             const int k = (e0 + u < c_hi ? e0 + u : c_hi - 1) - e_lo;
             src[u] = s_send[k];
             wv[u] = s_w[k];
             nid[u] = s_nid[k];
           }
 #pragma unroll
-          for (int u = 0; u < 8; ++u)
+          for (int u = 0; u < R; ++u)
             v[u] = *reinterpret_cast<const float4*>(a.h + static_cast<int64_t>(src[u]) * UA + 4 * gl);
 #pragma unroll
-          for (int u = 0; u < 8; ++u) {
+          for (int u = 0; u < R; ++u) {
             if (e0 + u < c_hi) {
               if (nid[u] != cur) {
                 if (cur >= 0) {
@@ -315,7 +326,10 @@ __global__ __launch_bounds__(256) void gcn_tile_kernel(GcnArgs a) {
               s.x += wv[u] * v[u].x; s.y += wv[u] * v[u].y; s.z += wv[u] * v[u].z; s.w += wv[u] * v[u].w;
             }
           }
-        }
+        };
+        int e0 = c_lo;
+        for (; c_hi - e0 >= 16; e0 += 16) round(e0, std::integral_constant<int, 16>());
+        for (; e0 < c_hi; e0 += 8) round(e0, std::integral_constant<int, 8>());
         if (cur >= 0) *reinterpret_cast<float4*>(part + slot * UA + 4 * gl) = s;
       }
       __syncthreads();
