@@ -10,12 +10,12 @@ Every buffer is allocated when a batch is bound; ``forward()`` only replays the 
 """
 import ctypes
 import os
-import sys
 
 import numpy as np
 import torch
 
 from . import _ffi
+from .result_ring import ResultRing
 
 
 _SSP = ("kgcnn>shifted_softplus", "shifted_softplus")
@@ -141,7 +141,7 @@ class FusedSchnet:
             self.flags_arg |= 64
         self.stream = torch.cuda.Stream()
         self.graph = None
-        self._ring, self._ring_next = [], 0
+        self._ring = None
         self.num_launches = 1 + 2 * depth + 1
         self._b = None
 
@@ -188,7 +188,6 @@ class FusedSchnet:
             rows -= 1
         self.out_rows = rows  # tf.math.segment_sum drops trailing empty graphs (kgcnn/layers/pooling.py:215-219)
         self._drop_graphs()
-        self._ring, self._ring_next = [], 0
         self._desc = self._desc_ref = None
 
     def _prepare(self):
@@ -269,51 +268,34 @@ class FusedSchnet:
         return exe
 
     # ------------------------------------------------------------------------------------------------ result ring
-    # A Keras model call returns a NEW tensor.  Copying the slot's static (G,1) buffer into a fresh allocation costs a
-    # launch of its own per forward (4.3 us of 64 at config 2).  Instead the slot keeps a few result buffers, each with
-    # its own captured graph (same kernels, same work buffers - only the readout's destination differs), and hands out
-    # a buffer only while nobody else holds it or a view of it (storage use count and Python reference count back at
-    # their idle values): to the caller that is indistinguishable from a fresh tensor, and a result somebody still
-    # holds is never written again.  No idle buffer -> the static buffer and a copy, as before.
-    RING = 3
-
-    @staticmethod
-    def _holders(t):
-        return torch._C._storage_Use_Count(t.untyped_storage()._cdata), sys.getrefcount(t)
-
     def run_graph_fresh(self):
-        """Replay the forward on torch's current stream into a result buffer nobody else references; returns that
-        ``(G', 1)`` tensor, or ``None`` when every ring buffer is still held by a caller."""
-        ring = self._ring
-        entry = None
-        for k in range(len(ring)):
-            cand = ring[(self._ring_next + k) % len(ring)]
-            if self._holders(cand[0]) == cand[2]:
-                entry = cand
-                self._ring_next = (self._ring_next + k + 1) % len(ring)
-                break
-        if entry is None:
-            if len(ring) >= self.RING:
-                return None
-            entry = [torch.zeros((self.G, 1), dtype=torch.float32, device="cuda"), None, None]
-            ring.append(entry)
-            entry[2] = self._holders(entry[0])
-            self._ring_next = 0
-        if entry[1] is None:
-            torch.cuda.current_stream().synchronize()
-            entry[1] = self._capture(entry[0])
-        _ffi.call("mp_graph_launch", entry[1], _ffi.stream())
-        return entry[0] if self.out_rows == self.G else entry[0][:self.out_rows]
+        """Replay the forward on torch's current stream into a result buffer nobody else references
+        (``result_ring.ResultRing``: own captured graph per buffer, no copy launch); returns that ``(G', 1)`` tensor, or
+        ``None`` when every ring buffer is still held by a caller."""
+        if self._ring is None:
+            self._ring = ResultRing()
+        got = self._ring.acquire(lambda: (torch.zeros((self.G, 1), dtype=torch.float32, device="cuda"),),
+                                 lambda bufs: self._capture_synced(bufs[0]))
+        if got is None:
+            return None
+        (out,), graph = got
+        _ffi.call("mp_graph_launch", graph, _ffi.stream())
+        return out if self.out_rows == self.G else out[:self.out_rows]
+
+    def _capture_synced(self, out):
+        torch.cuda.current_stream().synchronize()
+        return self._capture(out)
 
     def _drop_graphs(self):
-        for exe in [getattr(self, "graph", None)] + [e[1] for e in getattr(self, "_ring", [])]:
-            if exe is not None:
-                try:
-                    _ffi.call("mp_graph_destroy", exe)
-                except Exception:
-                    pass
+        if getattr(self, "graph", None) is not None:
+            try:
+                _ffi.call("mp_graph_destroy", self.graph)
+            except Exception:
+                pass
+        if getattr(self, "_ring", None) is not None:
+            self._ring.destroy()
         self.graph = None
-        self._ring = []
+        self._ring = None
 
     def run_current(self, how="graph"):
         """One forward of the bound batch on torch's CURRENT stream (ordinary stream semantics for the caller):
@@ -616,6 +598,10 @@ class SchnetFusedRoute:
         elif how == "direct":
             how = "eager"
         self.last = how
+        if how == "graph" and self.copy_output:
+            got = slot.run_graph_fresh()   # an (energy, force) pair nobody else holds: no copy launches
+            if got is not None:
+                return got
         eng, force = slot.run_current(how)
         return (eng.clone(), force.clone()) if self.copy_output else (eng, force)
 

@@ -9,11 +9,11 @@ tensors in place, keeps one batch slot per distinct input set (work buffers, ind
 torch's current stream and hands every call a result nobody else holds.
 """
 import ctypes
-import sys
 
 import torch
 
 from . import _ffi
+from .result_ring import ResultRing
 
 _SUM = ("sum", "segment_sum", "reduce_sum")
 _WIDTHS = (32, 64, 128)
@@ -52,8 +52,6 @@ class FusedGcn:
     """One batch slot: the index plan, the two (N, units) buffers the layers alternate between, result buffers and the
     captured graphs of ONE bound input set."""
 
-    RING = 3
-
     def __init__(self, route, node, edge_w, idx):
         self.route = route
         self.node, self.edge_w, self.idx = node, edge_w, idx
@@ -71,7 +69,7 @@ class FusedGcn:
         units = route.units
         self.h = [torch.empty((self.N, units), dtype=torch.float32, device=x.device) for _ in range(2)]
         self.out_units = route.out_units
-        self._ring, self._ring_next = [], 0
+        self._ring = ResultRing()
         self._static = None      # [out, graph] used when every ring buffer is held
         self.stream = torch.cuda.Stream()
         self.calls = 0
@@ -135,50 +133,35 @@ class FusedGcn:
                 _ffi.call("mp_graph_end", _ffi.stream(), ctypes.byref(exe))
         return exe
 
-    @staticmethod
-    def _holders(t):
-        return torch._C._storage_Use_Count(t.untyped_storage()._cdata), sys.getrefcount(t)
-
     def _new_out(self):
         return torch.empty((self.N, self.out_units), dtype=torch.float32, device=self.h[0].device)
 
     def run(self, how):
-        """One forward on torch's current stream; returns an (N, out_units) tensor nobody else holds."""
+        """One forward on torch's current stream; returns an (N, out_units) tensor nobody else holds
+        (``result_ring.ResultRing``)."""
         self.calls += 1
         if how != "graph":
             out = self._new_out()
             self._launch_all(self._descs(out))
             return out
-        ring, entry = self._ring, None
-        for k in range(len(ring)):
-            cand = ring[(self._ring_next + k) % len(ring)]
-            if self._holders(cand[0]) == cand[2]:
-                entry = cand
-                self._ring_next = (self._ring_next + k + 1) % len(ring)
-                break
-        if entry is None and len(ring) < self.RING:
-            entry = [self._new_out(), None, None]
-            ring.append(entry)
-            entry[2] = self._holders(entry[0])
-            self._ring_next = 0
-        if entry is None:                # every result buffer is still held by the caller: static buffer + copy
+        got = self._ring.acquire(lambda: (self._new_out(),), lambda bufs: self._capture(bufs[0]))
+        if got is None:                  # every result buffer is still held by the caller: static buffer + copy
             if self._static is None:
                 self._static = [self._new_out(), None]
                 self._static[1] = self._capture(self._static[0])
             _ffi.call("mp_graph_launch", self._static[1], _ffi.stream())
             return self._static[0].clone()
-        if entry[1] is None:
-            entry[1] = self._capture(entry[0])
-        _ffi.call("mp_graph_launch", entry[1], _ffi.stream())
-        return entry[0]
+        (out,), graph = got
+        _ffi.call("mp_graph_launch", graph, _ffi.stream())
+        return out
 
     def __del__(self):
-        for exe in [e[1] for e in getattr(self, "_ring", [])] + ([self._static[1]] if getattr(self, "_static", None) else []):
-            if exe is not None:
-                try:
-                    _ffi.call("mp_graph_destroy", exe)
-                except Exception:
-                    pass
+        try:
+            self._ring.destroy()
+            if self._static is not None and self._static[1] is not None:
+                _ffi.call("mp_graph_destroy", self._static[1])
+        except Exception:
+            pass
 
 
 class GcnFusedRoute:

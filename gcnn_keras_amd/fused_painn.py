@@ -20,6 +20,7 @@ import numpy as np
 import torch
 
 from . import _ffi
+from .result_ring import ResultRing
 
 _SUM = ("sum", "segment_sum", "reduce_sum")
 _CONST_INIT = {"zeros": 0.0, "eps": 1e-7, "ones": 1.0}
@@ -113,6 +114,7 @@ class FusedPainn:
         self.fast_readout = len(self.out_units) == 2 and self.out_units[0] in (64, 128) and self.out_units[1] == 1
         self.stream = torch.cuda.Stream()
         self.graphs = {}
+        self.rings = {}
         self.calls = 0
 
     # ------------------------------------------------------------------------------------------------ binding
@@ -165,6 +167,7 @@ class FusedPainn:
             self.g_d, self.g_rij = e(2, mm), e(2, mm, 3)   # one slice per feature half of the reverse message kernel
             self.force = e(n, 3)
         self.graphs = {}
+        self.rings = {}
 
     # ------------------------------------------------------------------------------------------------ launches
     @staticmethod
@@ -285,22 +288,59 @@ class FusedPainn:
         if how == "graph":
             graph = self.graphs.get(bool(with_forces))
             if graph is None:
-                torch.cuda.current_stream().synchronize()
-                with torch.cuda.stream(self.stream):
-                    self._launch(with_forces)   # warm-up outside capture
-                    self.stream.synchronize()
-                    _ffi.call("mp_graph_begin", _ffi.stream())
-                    try:
-                        self._launch(with_forces)
-                    finally:
-                        exe = ctypes.c_void_p()
-                        _ffi.call("mp_graph_end", _ffi.stream(), ctypes.byref(exe))
-                graph = self.graphs[bool(with_forces)] = exe
+                graph = self.graphs[bool(with_forces)] = self._capture(with_forces)
             _ffi.call("mp_graph_launch", graph, _ffi.stream())
         else:
             self._launch(with_forces)
         eng = self.post_out[-1]
         return (eng if self.out_rows == self.G else eng[:self.out_rows]), (self.force if with_forces else None)
+
+    def _capture(self, with_forces, eng=None, force=None):
+        """Capture the launches of one pass on the slot's private stream; ``eng`` / ``force``: result buffers other than
+        the static ones (a result-ring entry) - the last kernels of the captured pass write there."""
+        saved = (self.post_out[-1], getattr(self, "force", None))
+        if eng is not None:
+            self.post_out[-1] = eng
+        if force is not None:
+            self.force = force
+        try:
+            torch.cuda.current_stream().synchronize()
+            with torch.cuda.stream(self.stream):
+                self._launch(with_forces)   # warm-up outside capture
+                self.stream.synchronize()
+                _ffi.call("mp_graph_begin", _ffi.stream())
+                try:
+                    self._launch(with_forces)
+                finally:
+                    exe = ctypes.c_void_p()
+                    _ffi.call("mp_graph_end", _ffi.stream(), ctypes.byref(exe))
+        finally:
+            self.post_out[-1] = saved[0]
+            if force is not None:
+                self.force = saved[1]
+        return exe
+
+    def run_graph_fresh(self, with_forces):
+        """Graph replay into result tensors nobody else holds (``result_ring.ResultRing``: no copy launches): returns
+        ``(energy (G', L), force (N, 3) | None)``, or ``None`` when every set of the ring is still held."""
+        if with_forces and not self.grad:
+            raise _ffi.EngineError("this batch was bound without the reverse-pass buffers")
+        ring = self.rings.get(bool(with_forces))
+        if ring is None:
+            ring = self.rings[bool(with_forces)] = ResultRing()
+        like = self.post_out[-1]
+
+        def make():
+            bufs = (torch.empty_like(like),)
+            return bufs + ((torch.empty_like(self.force),) if with_forces else ())
+
+        got = ring.acquire(make, lambda bufs: self._capture(with_forces, bufs[0], bufs[1] if with_forces else None))
+        if got is None:
+            return None
+        bufs, graph = got
+        _ffi.call("mp_graph_launch", graph, _ffi.stream())
+        eng = bufs[0]
+        return (eng if self.out_rows == self.G else eng[:self.out_rows]), (bufs[1] if with_forces else None)
 
     def check_flags(self):
         f = int(self.flags.item())
@@ -311,6 +351,8 @@ class FusedPainn:
         try:
             for g in self.graphs.values():
                 _ffi.call("mp_graph_destroy", g)
+            for ring in self.rings.values():
+                ring.destroy()
         except Exception:
             pass
 
@@ -391,6 +433,10 @@ class PainnFusedRoute:
 
     def __call__(self, inputs):
         slot, how = self._slot(inputs, grad=False)
+        if how == "graph" and self.copy_output:
+            got = slot.run_graph_fresh(False)   # a result buffer nobody else holds: no copy launch
+            if got is not None:
+                return got[0]
         eng, _ = slot.run_current(False, how)
         return eng.clone() if self.copy_output else eng
 
@@ -399,6 +445,10 @@ class PainnFusedRoute:
         if not self.single_state:
             raise ValueError("fused forces are built for one energy state")
         slot, how = self._slot(inputs, grad=True)
+        if how == "graph" and self.copy_output:
+            got = slot.run_graph_fresh(True)
+            if got is not None:
+                return got
         eng, force = slot.run_current(True, how)
         return (eng.clone(), force.clone()) if self.copy_output else (eng, force)
 

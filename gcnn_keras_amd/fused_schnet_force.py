@@ -21,6 +21,7 @@ import ctypes
 import torch
 
 from . import _ffi
+from .result_ring import ResultRing
 
 
 def _transposed_names(depth, linear_head):
@@ -102,9 +103,14 @@ class FusedSchnetForce:
         self._desc = self._descriptor()
         self._desc_ref = ctypes.byref(self._desc)
         self._launch_fn = _ffi.lib().mp_schnet_force_launch
-        self.graph = None
+        self._drop_graphs()
+        self._ring = ResultRing()
 
-    def _descriptor(self):
+    def _descriptor(self, energy=None, force=None):
+        """``mp_schnet_force_desc`` of the bound batch; ``energy`` / ``force``: result buffers other than the static
+        ones (a result-ring entry)."""
+        energy = self.energy if energy is None else energy
+        force = self.force if force is None else force
         p, w, gw, ga = self.p, self.w["node"], self.gw, self.gauss
         node, xyz, idx = self.inputs
         f = _ffi.SchnetForceDesc()
@@ -135,7 +141,7 @@ class FusedSchnetForce:
             d.Wo0, d.bo0 = addr(p["output_mlp/0/kernel"]), addr(p.get("output_mlp/0/bias"))
             d.Wo1, d.bo1 = addr(p["output_mlp/1/kernel"]), addr(p.get("output_mlp/1/bias"))
         d.recv, d.send, d.dist, d.flags_word = addr(self.recv), addr(self.send), addr(self.dist), addr(self.flags)
-        d.n, d.x, d.agg, d.h, d.out = addr(self.n), None, addr(self.agg), addr(self.h), addr(self.energy)
+        d.n, d.x, d.agg, d.h, d.out = addr(self.n), None, addr(self.agg), addr(self.h), addr(energy)
         f.xs, f.d2, f.dl0, f.dl1 = addr(self.xs), addr(self.d2), addr(self.dl0), addr(self.dl1)
         f.g_pool, f.node_graph = addr(self.g_pool), addr(self.node_graph)
         f.Wl0T, f.Wl1T = addr(T["last_mlp/0/kernel"]), addr(T["last_mlp/1/kernel"])
@@ -144,33 +150,64 @@ class FusedSchnetForce:
         f.seg1, f.perm1 = (None, None) if self.perm1 is None else (addr(self.seg1), addr(self.perm1))
         f.ptr0, f.ptr1 = addr(self.ptr0), addr(self.ptr1)
         f.g_n, f.g_agg, f.g_x, f.g_d, f.force = (addr(self.g_n), addr(self.g_agg), addr(self.g_x), addr(self.g_d),
-                                                  addr(self.force))
+                                                  addr(force))
         f.force_scale = -1.0
         return f
 
-    def _launch(self):
-        _ffi.check(self._launch_fn(self._desc_ref, ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)))
+    def _launch(self, desc_ref=None):
+        _ffi.check(self._launch_fn(self._desc_ref if desc_ref is None else desc_ref,
+                                   ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)))
+
+    def _capture(self, desc_ref=None):
+        torch.cuda.current_stream().synchronize()
+        with torch.cuda.stream(self.stream):
+            self._launch(desc_ref)
+            self.stream.synchronize()
+            _ffi.call("mp_graph_begin", _ffi.stream())
+            try:
+                self._launch(desc_ref)
+            finally:
+                exe = ctypes.c_void_p()
+                _ffi.call("mp_graph_end", _ffi.stream(), ctypes.byref(exe))
+        return exe
+
+    def _capture_into(self, bufs):
+        desc = self._descriptor(bufs[0], bufs[1])
+        return self._capture(ctypes.byref(desc))   # the descriptor is read at launch (capture) time only
 
     def run_current(self, how="graph"):
         """Energy ``(G', 1)`` and physical force ``(N, 3)`` of the bound batch on torch's current stream (static buffers)."""
         if how == "graph":
             if self.graph is None:
-                torch.cuda.current_stream().synchronize()
-                with torch.cuda.stream(self.stream):
-                    self._launch()
-                    self.stream.synchronize()
-                    _ffi.call("mp_graph_begin", _ffi.stream())
-                    try:
-                        self._launch()
-                    finally:
-                        exe = ctypes.c_void_p()
-                        _ffi.call("mp_graph_end", _ffi.stream(), ctypes.byref(exe))
-                self.graph = exe
+                self.graph = self._capture()
             _ffi.call("mp_graph_launch", self.graph, _ffi.stream())
         else:
             self._launch()
         eng = self.energy if self.out_rows == self.G else self.energy[:self.out_rows]
         return eng, self.force
+
+    def run_graph_fresh(self):
+        """Graph replay into an (energy, force) pair nobody else holds (``result_ring.ResultRing``: no copy launches), or
+        ``None`` when every pair of the ring is still held."""
+        dev = self.energy.device
+        got = self._ring.acquire(lambda: (torch.empty((self.G, 1), dtype=torch.float32, device=dev),
+                                          torch.empty((self.N, 3), dtype=torch.float32, device=dev)),
+                                 self._capture_into)
+        if got is None:
+            return None
+        (eng, force), graph = got
+        _ffi.call("mp_graph_launch", graph, _ffi.stream())
+        return (eng if self.out_rows == self.G else eng[:self.out_rows]), force
+
+    def _drop_graphs(self):
+        if getattr(self, "graph", None) is not None:
+            try:
+                _ffi.call("mp_graph_destroy", self.graph)
+            except Exception:
+                pass
+        if getattr(self, "_ring", None) is not None:
+            self._ring.destroy()
+        self.graph = None
 
     def check_flags(self):
         if int(self.flags.item()) & _ffi.MP_FLAG_OOB:
@@ -178,7 +215,6 @@ class FusedSchnetForce:
 
     def __del__(self):
         try:
-            if self.graph is not None:
-                _ffi.call("mp_graph_destroy", self.graph)
+            self._drop_graphs()
         except Exception:
             pass

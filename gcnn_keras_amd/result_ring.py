@@ -1,0 +1,58 @@
+"""Result buffers of a batch slot.
+
+A Keras model call returns a NEW tensor.  A captured HIP graph writes to fixed addresses, so the fused routes used to copy
+the slot's static result into a fresh allocation after every replay - a launch of its own per result (4.3 us of a 64 us
+SchNet forward at BASELINE config 2).  Instead a slot keeps a few result sets, each with its own captured graph (the same
+kernels on the same work buffers - only the destination of the final kernels differs), and hands a set out only while
+nobody else holds one of its tensors or a view of them: storage use count and Python reference count are back at the
+values they had when only the ring held the tensor.  To the caller that is indistinguishable from a fresh tensor - a
+result somebody still holds is never written again - and a loop that drops its results runs on the ring alone.  When
+every set is held the caller falls back to a static set and a copy.
+"""
+import sys
+
+import torch
+
+from . import _ffi
+
+
+def _holders(t):
+    return torch._C._storage_Use_Count(t.untyped_storage()._cdata), sys.getrefcount(t)
+
+
+class ResultRing:
+
+    def __init__(self, size=3):
+        self.size = int(size)
+        self._entries, self._next = [], 0      # entry: [tensors, graph, idle holder counts]
+
+    def acquire(self, make, capture):
+        """``(tensors, graph)`` of a result set no caller holds, or ``None`` when all are held.  ``make() -> tuple of
+        tensors`` allocates a set, ``capture(tensors) -> graph`` captures the slot's launches writing into it (both
+        passed per call, so the ring holds no reference back to its slot)."""
+        ring, entry = self._entries, None
+        for k in range(len(ring)):
+            cand = ring[(self._next + k) % len(ring)]
+            if all(_holders(cand[0][i]) == cand[2][i] for i in range(len(cand[0]))):
+                entry = cand
+                self._next = (self._next + k + 1) % len(ring)
+                break
+        if entry is None:
+            if len(ring) >= self.size:
+                return None
+            entry = [tuple(make()), None, None]
+            ring.append(entry)
+            entry[2] = [_holders(entry[0][i]) for i in range(len(entry[0]))]
+            self._next = 0
+        if entry[1] is None:
+            entry[1] = capture(entry[0])
+        return entry[0], entry[1]
+
+    def destroy(self):
+        for entry in self._entries:
+            if entry[1] is not None:
+                try:
+                    _ffi.call("mp_graph_destroy", entry[1])
+                except Exception:
+                    pass
+        self._entries = []

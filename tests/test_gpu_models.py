@@ -479,3 +479,37 @@ def test_gcn_fused_route_equals_layer_sequence(units, mlp_units, mlp_act, sort_e
                               ko.R(idxs, es), depth=2, output_mlp_act=tuple(mlp_act)).values
     _check(got, oracle(np.float32), oracle(np.float64))
     _check(layers, oracle(np.float32), oracle(np.float64))
+
+
+def test_gcn_fused_route_padded_output():
+    """``output_to_tensor=True`` (kgcnn/literature/GCN.py:108-109: ChangeTensorType ragged -> tensor) behind the fused
+    route: several graphs are padded by the cast layer, a single graph's padded tensor is the value matrix itself."""
+    from gcnn_keras_amd.literature import GCN
+    for sizes in ([30], [12, 30, 5]):
+        rng = np.random.default_rng(len(sizes))
+        attrs = rng.normal(size=(sum(sizes), 20)).astype(np.float32)
+        ns = np.concatenate([[0], np.cumsum(sizes)]).astype(np.int64)
+        idx = [np.stack([np.sort(rng.integers(0, n, size=3 * n)), rng.integers(0, n, size=3 * n)], 1) for n in sizes]
+        es = np.concatenate([[0], np.cumsum([len(i) for i in idx])]).astype(np.int64)
+        idx = np.concatenate(idx).astype(np.int64)
+        wts = rng.uniform(0.1, 1.0, size=(len(idx), 1)).astype(np.float32)
+        p = synth.gcn_params(seed=5, depth=1, in_features=20, units=32, out_units=(8,), random_bias=True)
+        outs = []
+        for to_tensor in (False, True):
+            model = GCN.make_model(
+                inputs=[{"shape": (None, 20), "name": "node_attributes", "dtype": "float32", "ragged": True},
+                        {"shape": (None, 1), "name": "edge_weights", "dtype": "float32", "ragged": True},
+                        {"shape": (None, 2), "name": "edge_indices", "dtype": "int64", "ragged": True}],
+                gcn_args={"units": 32, "use_bias": True, "activation": "relu", "pooling_method": "sum"},
+                depth=1, output_embedding="node", output_to_tensor=to_tensor,
+                output_mlp={"use_bias": True, "units": [8], "activation": "linear"})
+            model.set_weights(list(p.values()))
+            ins = [_dev(attrs, ns), _dev(wts, es), _dev(idx, es)]
+            model(ins)
+            outs.append(model(ins))
+            assert model.fused.last == "graph"
+        ragged, padded = outs[0].values.cpu().numpy(), outs[1].cpu().numpy()
+        assert padded.shape == (len(sizes), max(sizes), 8)
+        for g, n in enumerate(sizes):
+            assert np.array_equal(padded[g, :n], ragged[ns[g]:ns[g + 1]])
+            assert not padded[g, n:].any()
