@@ -399,9 +399,13 @@ __global__ __launch_bounds__(512, 1) void painn_update_bwd_chain_kernel(UpdateBw
     const bool in = t < a.ntiles && row < a.N;
     const int64_t rs = in ? row : 0;
     gz = *reinterpret_cast<const float4*>(a.gz2 + rs * UPD_F + ef);
-    gv0 = *reinterpret_cast<const float4*>(a.gv2 + (rs * 3 + 0) * UPD_F + ef);
-    gv1 = *reinterpret_cast<const float4*>(a.gv2 + (rs * 3 + 1) * UPD_F + ef);
-    gv2 = *reinterpret_cast<const float4*>(a.gv2 + (rs * 3 + 2) * UPD_F + ef);
+    if (a.gv2) {   // wave-uniform; null = no gradient reaches v'' (the last block: the readout sees z only)
+      gv0 = *reinterpret_cast<const float4*>(a.gv2 + (rs * 3 + 0) * UPD_F + ef);
+      gv1 = *reinterpret_cast<const float4*>(a.gv2 + (rs * 3 + 1) * UPD_F + ef);
+      gv2 = *reinterpret_cast<const float4*>(a.gv2 + (rs * 3 + 2) * UPD_F + ef);
+    } else {
+      gv0 = gv1 = gv2 = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
     vu0 = *reinterpret_cast<const float4*>(a.uv + ((rs * 3 + 0) * 2) * UPD_F + ef);
     vv0 = *reinterpret_cast<const float4*>(a.uv + ((rs * 3 + 0) * 2 + 1) * UPD_F + ef);
     vu1 = *reinterpret_cast<const float4*>(a.uv + ((rs * 3 + 1) * 2) * UPD_F + ef);
@@ -627,7 +631,7 @@ int mp_painn_update_fused_bwd_f32(const float* g_z2, const float* g_v2, const fl
   MP_REQUIRE(N >= 0, "mp_painn_update_fused_bwd_f32: bad size");
   MP_REQUIRE(act1 >= MP_ACT_LINEAR && act1 <= MP_ACT_LAST, "mp_painn_update_fused_bwd_f32: unknown activation %d", act1);
   if (N == 0) return MP_OK;
-  MP_REQUIRE(g_z2 && g_v2 && uv && prod && a && c && W1T_packed && grad_pre && W2T_packed && g_z && g_uv,
+  MP_REQUIRE(g_z2 && uv && prod && a && c && W1T_packed && grad_pre && W2T_packed && g_z && g_uv,
              "mp_painn_update_fused_bwd_f32: null pointer");
   UpdateBwdArgs q{};
   q.N = N; q.ntiles = static_cast<int>((N + 15) / 16);

@@ -250,17 +250,18 @@ class FusedPainn:
         if not self.fast_readout:
             _ffi.call("mp_repeat_rows_f32", _ffi.ptr(t), _ffi.ptr(node.row_splits), self.G, 128, n, _ffi.ptr(self.gz),
                       _ffi.stream())
-        self.gv.zero_()                 # the readout sees z only
+        # the readout sees z only: no gradient reaches the last block's v'' (null pointer = zeros, no fill launch)
         for i in range(self.depth - 1, -1, -1):
             c, u = "conv%d/" % i, "update%d/" % i
             b = self.blk[i]
             v_in = self.v0 if i == 0 else self.vs[i - 1]
             # reverse of the fused PAiNNUpdate: post_bwd / pre_bwd as prologue / epilogue of the transposed chain
-            _ffi.call("mp_painn_update_fused_bwd_f32", _ffi.ptr(self.gz), _ffi.ptr(self.gv), _ffi.ptr(b["uv"]),
+            gv_in = self.gv if i < self.depth - 1 else None
+            _ffi.call("mp_painn_update_fused_bwd_f32", _ffi.ptr(self.gz), _ffi.ptr(gv_in), _ffi.ptr(b["uv"]),
                       _ffi.ptr(b["prod"]), _ffi.ptr(b["a"]), _ffi.ptr(b["c"]), n, _ffi.ptr(w[u + "a/TP"]), self.act_upd,
                       0.0, _ffi.ptr(b["h2"]), _ffi.ptr(w[u + "dense1/TP"]), _ffi.ptr(self.g_zp), _ffi.ptr(self.g_uv),
                       _ffi.stream())
-            self._chain(self.g_uv, 3 * n, 256, w["uvT%d/P" % i], None, 128, self.g_vp, addend=self.gv)
+            self._chain(self.g_uv, 3 * n, 256, w["uvT%d/P" % i], None, 128, self.g_vp, addend=gv_in)
             _ffi.call("mp_painn_message_bwd_f32", _ffi.ptr(b["s"]), _ffi.ptr(v_in), n, _ffi.ptr(self.rbf),
                       _ffi.ptr(self.rbfd), self.B, _ffi.ptr(self.env), _ffi.ptr(self.envd), _ffi.ptr(self.rij),
                       _ffi.ptr(p[c + "w/kernel"]), _ffi.ptr(p.get(c + "w/bias")), _ffi.ptr(self.ptr1),

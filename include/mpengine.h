@@ -338,7 +338,8 @@ int mp_painn_update_fused_f32(const float* z, const float* v, const float* uv, i
                               const float* b2, float* c_out, float* prod_out, float* a_out, float* z2, float* v2,
                               mpStream_t stream);
 /* ... and its reverse in one launch: post_bwd as the prologue, pre_bwd as the epilogue of the chain against the transposed
- * kernels (W1T (384,128) = Wa^T, W2T (128,256) = Wd^T as mp_chain_pack_f32 images; grad_pre = the saved c Wd + bd). */
+ * kernels (W1T (384,128) = Wa^T, W2T (128,256) = Wd^T as mp_chain_pack_f32 images; grad_pre = the saved c Wd + bd).
+ * g_v2 == NULL: no gradient reaches v'' (the last block of an energy model, whose readout sees z only). */
 int mp_painn_update_fused_bwd_f32(const float* g_z2, const float* g_v2, const float* uv, const float* prod, const float* a,
                                   const float* c, int64_t N, const float* W1T_packed, int act1, float alpha1,
                                   const float* grad_pre, const float* W2T_packed, float* g_z, float* g_uv,

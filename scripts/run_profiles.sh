@@ -9,7 +9,10 @@ rocprofv3 --kernel-trace --stats -d gpurun_out/prof5_c2_1 -o b -- $B --in-flight
 rocprofv3 --kernel-trace --stats -d gpurun_out/prof5_c2_4 -o b -- $B > gpurun_out/prof5_c2_4.log 2>&1
 rocprofv3 --kernel-trace --stats -d gpurun_out/prof5_sf -o sf -- python3 scripts/bench_schnet_force.py 64 --profile fork 200 > gpurun_out/prof5_sf.log 2>&1
 rocprofv3 --kernel-trace --stats -d gpurun_out/prof5_pn_ef -o painn -- python3 scripts/profile_painn.py force 200 > gpurun_out/prof5_pn_ef.log 2>&1
+rocprofv3 --kernel-trace --stats -d gpurun_out/prof5_pn_f -o painn -- python3 scripts/profile_painn.py forward 200 > gpurun_out/prof5_pn_f.log 2>&1
+rocprofv3 --kernel-trace --stats -d gpurun_out/prof5_gcn -o gcn -- python3 scripts/profile_gcn.py 300 > gpurun_out/prof5_gcn.log 2>&1
 echo traces done
+if [ -n "$SKIP_PMC" ]; then exit 0; fi
 for c in FETCH_SIZE WRITE_SIZE; do
   n=$(echo $c | tr A-Z a-z | cut -d_ -f1)
   rocprofv3 --pmc $c --kernel-trace --output-format csv -d gpurun_out/pmc2_$n -o p -- python3 bench.py --no-cpu-baseline --no-config4-reference --steps 200 --in-flight 1 > gpurun_out/pmc2_$n.log 2>&1
