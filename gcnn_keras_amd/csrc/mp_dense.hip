@@ -69,41 +69,53 @@ __global__ __launch_bounds__(256) void dense_mfma_kernel(const float* __restrict
   constexpr int NS = (BM * BK) / 256;         // floats per thread and tile, scalar path
   float4 ra4[VEC ? NV : 1], rb4[VEC ? NV : 1], rp4[(VEC && IN_MODE == 2) ? NV : 1];
   float ra[VEC ? 1 : NS], rb[VEC ? 1 : NS], rp[(!VEC && IN_MODE == 2) ? NS : 1];
+  // Every load of a tile is UNCONDITIONAL, from an address clamped into the operand (row R-1 / the slice's last k / the
+  // last column group); what lies outside is zeroed when the registers are written to LDS (store_tile).  With the loads
+  // behind `ok ? load : 0` hipcc emits one branch per load and, between the fifth and sixth of a tile's eight loads, an
+  // s_waitcnt vmcnt(0): the prefetch of the next k tile then costs a full memory round trip in FRONT of the MFMA loop that
+  // was meant to cover it (seen in the ISA; every k tile of every layer-path Dense paid it).
+  const int64_t r_last = R - 1;
   auto load_tile = [&](int64_t k0) {
     if constexpr (VEC) {
+      const int64_t k_last = K - 4, c_last = U - 4;    // VEC: K, U multiples of 4
 #pragma unroll
       for (int i = 0; i < NV; ++i) {
         const int idx = tid + i * 256;
         const int ar = idx / (BK / 4), ac = (idx % (BK / 4)) * 4;
-        const int64_t gr = row0 + ar, gk = k0 + ac;
-        const bool ok = gr < R && gk < K;
-        ra4[i] = ok ? *reinterpret_cast<const float4*>(x + gr * xld + gk) : make_float4(0.f, 0.f, 0.f, 0.f);
-        if constexpr (IN_MODE == 2)
-          rp4[i] = ok ? *reinterpret_cast<const float4*>(ex.in_pre + gr * xld + gk) : make_float4(0.f, 0.f, 0.f, 0.f);
+        int64_t gr = row0 + ar, gk = k0 + ac;
+        gr = gr < R ? gr : r_last;
+        gk = gk < K ? gk : k_last;
+        ra4[i] = *reinterpret_cast<const float4*>(x + gr * xld + gk);
+        if constexpr (IN_MODE == 2) rp4[i] = *reinterpret_cast<const float4*>(ex.in_pre + gr * xld + gk);
         const int br = idx / (BN / 4), bc = (idx % (BN / 4)) * 4;
-        const int64_t gk2 = k0 + br, gc = col0 + bc;
-        rb4[i] = (gk2 < K && gc < U) ? *reinterpret_cast<const float4*>(W + gk2 * U + gc) : make_float4(0.f, 0.f, 0.f, 0.f);
+        int64_t gk2 = k0 + br, gc = col0 + bc;
+        gk2 = gk2 < K ? gk2 : K - 1;
+        gc = gc < U ? gc : c_last;
+        rb4[i] = *reinterpret_cast<const float4*>(W + gk2 * U + gc);
       }
     } else {
 #pragma unroll
       for (int i = 0; i < NS; ++i) {
         const int idx = tid + i * 256;
         const int ar = idx / BK, ac = idx % BK;
-        const int64_t gr = row0 + ar, gk = k0 + ac;
-        const bool ok = gr < R && gk < K;
-        ra[i] = ok ? x[gr * xld + gk] : 0.0f;
-        if constexpr (IN_MODE == 2) rp[i] = ok ? ex.in_pre[gr * xld + gk] : 0.0f;
+        int64_t gr = row0 + ar, gk = k0 + ac;
+        gr = gr < R ? gr : r_last;
+        gk = gk < K ? gk : K - 1;
+        ra[i] = x[gr * xld + gk];
+        if constexpr (IN_MODE == 2) rp[i] = ex.in_pre[gr * xld + gk];
         const int br = idx / BN, bc = idx % BN;
-        const int64_t gk2 = k0 + br, gc = col0 + bc;
-        rb[i] = (gk2 < K && gc < U) ? W[gk2 * U + gc] : 0.0f;
+        int64_t gk2 = k0 + br, gc = col0 + bc;
+        gk2 = gk2 < K ? gk2 : K - 1;
+        gc = gc < U ? gc : U - 1;
+        rb[i] = W[gk2 * U + gc];
       }
     }
   };
-  // the staged value: act(x) / x * act'(pre); padding stays exactly 0 (act(0) need not be 0, act'(0) * 0 is)
+  // the staged value: act(x) / x * act'(pre); padding is exactly 0 (act(0) need not be 0, act'(0) * 0 is)
   auto prologue = [&](float xv, float pv, bool ok) -> float {
     if constexpr (IN_MODE == 1) return ok ? mp_apply_act(ex.in_act, ex.in_alpha, xv) : 0.0f;
-    if constexpr (IN_MODE == 2) return xv * mp_act_grad(ex.in_act, ex.in_alpha, pv);
-    return xv;
+    if constexpr (IN_MODE == 2) return ok ? xv * mp_act_grad(ex.in_act, ex.in_alpha, pv) : 0.0f;
+    return ok ? xv : 0.0f;
   };
   auto store_tile = [&](int64_t k0) {
     if constexpr (VEC) {
@@ -118,7 +130,8 @@ __global__ __launch_bounds__(256) void dense_mfma_kernel(const float* __restrict
         d[1] = prologue(ra4[i].y, pv.y, ok);
         d[2] = prologue(ra4[i].z, pv.z, ok);
         d[3] = prologue(ra4[i].w, pv.w, ok);
-        *reinterpret_cast<float4*>(Bs + idx * 4) = rb4[i];
+        const bool okb = (k0 + idx / (BN / 4)) < K && (col0 + (idx % (BN / 4)) * 4) < U;
+        *reinterpret_cast<float4*>(Bs + idx * 4) = okb ? rb4[i] : make_float4(0.f, 0.f, 0.f, 0.f);
       }
     } else {
 #pragma unroll
@@ -126,7 +139,8 @@ __global__ __launch_bounds__(256) void dense_mfma_kernel(const float* __restrict
         const int idx = tid + i * 256;
         const bool ok = (row0 + idx / BK) < R && (k0 + idx % BK) < K;
         As[(idx / BK) * A_LD + (idx % BK)] = prologue(ra[i], (IN_MODE == 2) ? rp[i] : 0.0f, ok);
-        Bs[idx] = rb[i];
+        const bool okb = (k0 + idx / BN) < K && (col0 + idx % BN) < U;
+        Bs[idx] = okb ? rb[i] : 0.0f;
       }
     }
   };
