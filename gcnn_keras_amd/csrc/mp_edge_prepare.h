@@ -64,6 +64,19 @@ __device__ __forceinline__ void edge_prepare_body(const EdgePrepArgs& p, int64_t
   const int64_t M = p.M, G = p.G, N = p.N;
   __shared__ int64_t s_es[LDS_SPLITS ? PREP_LDS_GRAPHS + 1 : 1];
   __shared__ int64_t s_ns[LDS_SPLITS ? PREP_LDS_GRAPHS + 1 : 1];
+  // The index row of an edge (and the row before it, for the sortedness test) does not depend on the owner search: it
+  // is requested first - together with the row_splits staging, one round trip instead of three in a row (staging ->
+  // index row -> previous row) - and the next iteration's rows are requested while this one is processed.  Rows past
+  // the end re-read the last row (unused).
+  const longlong2* __restrict__ idx2 = reinterpret_cast<const longlong2*>(idx);
+  const int64_t e_first = block * blockDim.x + threadIdx.x;
+  longlong2 v_pre = {0, 0}, pv_pre = {0, 0};
+  auto fetch_rows = [&](int64_t e) {
+    const int64_t ec = e < M ? e : M - 1;
+    v_pre = idx2[ec];
+    pv_pre = idx2[ec > 0 ? ec - 1 : 0];
+  };
+  if (M > 0) fetch_rows(e_first);
   if constexpr (LDS_SPLITS) {
     for (int i = threadIdx.x; i <= G; i += blockDim.x) {
       s_es[i] = edge_splits[i];
@@ -73,7 +86,9 @@ __device__ __forceinline__ void edge_prepare_body(const EdgePrepArgs& p, int64_t
   }
   const int64_t stride = nblocks * blockDim.x;
   int local_flags = 0;
-  for (int64_t e = block * blockDim.x + threadIdx.x; e - (threadIdx.x & 63) < M; e += stride) {
+  for (int64_t e = e_first; e - (threadIdx.x & 63) < M; e += stride) {
+    const longlong2 v = v_pre, pv = pv_pre;
+    fetch_rows(e + stride);
     int64_t g, base, n_g, g_start;
     if constexpr (LDS_SPLITS) {
       if (e >= M) continue;
@@ -90,7 +105,6 @@ __device__ __forceinline__ void edge_prepare_body(const EdgePrepArgs& p, int64_t
       n_g = node_splits[g + 1] - base;
       g_start = edge_splits[g];
     }
-    const longlong2 v = reinterpret_cast<const longlong2*>(idx)[e];
     int64_t i = v.x, j = v.y;
     if (i < 0 || i >= n_g || j < 0 || j >= n_g) {
       local_flags |= MP_FLAG_OOB;
@@ -106,12 +120,9 @@ __device__ __forceinline__ void edge_prepare_body(const EdgePrepArgs& p, int64_t
     // receiver of the previous edge: only the same graph can break the order (an earlier graph's ids are smaller
     // because node offsets grow with the graph index)
     if (g_start < e) {
+      if (pv.x + base > si) local_flags |= MP_FLAG_UNSORTED_COL0;
       if constexpr (COL1) {
-        const longlong2 pv = reinterpret_cast<const longlong2*>(idx)[e - 1];
-        if (pv.x + base > si) local_flags |= MP_FLAG_UNSORTED_COL0;
         if (pv.y + base > sj) local_flags |= MP_FLAG_UNSORTED_COL1;
-      } else {
-        if (idx[(e - 1) * 2] + base > si) local_flags |= MP_FLAG_UNSORTED_COL0;
       }
     }
     if (p.dist || Extra::active) {

@@ -110,23 +110,43 @@ __device__ __forceinline__ void schnet_node_body(const NodeArgs& a, int block, i
   constexpr int SV_IN = (TN * E) / 256;      // floats per thread (NODE_IN: embedding rows)
   constexpr int SV = (TN * F / 4) / 256;     // float4 per thread (aggregation rows)
   float stg_in[MODE == NODE_IN ? SV_IN : 1];
+  unsigned stg_ok = 0u;   // NODE_IN: bit j = element j of stg_in is a real embedding element (else 0)
   float4 stg[MODE == NODE_IN ? 1 : SV];
   auto stage_load = [&](int t) {
     const int64_t n0 = static_cast<int64_t>(t) * TN;
     if constexpr (MODE == NODE_IN) {
+      // two unconditional phases - every node number of the thread's elements, then every embedding element - so that the
+      // chain is two round trips; written as one guarded (number -> element) pair per element the compiler waits for each
+      // load before it issues the next: 2 * SV_IN dependent round trips (seen in the ISA, ~3 of stage 0's 5.2 us)
+      const bool live = t < a.ntiles;
+      const int64_t n_last = a.N > 0 ? a.N - 1 : 0;
+      int z[SV_IN];
+      if (a.numbers_i64) {
+#pragma unroll
+        for (int j = 0; j < SV_IN; ++j) {
+          const int64_t node = n0 + (tid + j * 256) / E;
+          z[j] = static_cast<int>(static_cast<const int64_t*>(a.numbers)[(live && node < a.N) ? node : n_last]);
+        }
+      } else {
+#pragma unroll
+        for (int j = 0; j < SV_IN; ++j) {
+          const int64_t node = n0 + (tid + j * 256) / E;
+          // Keras Embedding casts its input to int32
+          z[j] = static_cast<int>(static_cast<const float*>(a.numbers)[(live && node < a.N) ? node : n_last]);
+        }
+      }
 #pragma unroll
       for (int j = 0; j < SV_IN; ++j) {
-        const int i = tid + j * 256;
-        const int r = i / E, k = i % E;
-        const int64_t node = n0 + r;
-        float v = 0.0f;
-        if (t < a.ntiles && node < a.N) {
-          // Keras Embedding casts its input to int32
-          const int z = a.numbers_i64 ? static_cast<int>(static_cast<const int64_t*>(a.numbers)[node])
-                                      : static_cast<int>(static_cast<const float*>(a.numbers)[node]);
-          if (z >= 0 && z < a.vocab) v = a.emb[static_cast<int64_t>(z) * E + k];
-        }
-        stg_in[j] = v;
+        const int zc = z[j] < 0 ? 0 : (z[j] >= a.vocab ? a.vocab - 1 : z[j]);
+        stg_in[j] = a.emb[static_cast<int64_t>(zc) * E + (tid + j * 256) % E];
+      }
+      // validity is applied when the registers are written to LDS (stage_store): a select here would make the wave wait
+      // for the embedding elements before it requests its weight slices
+      stg_ok = 0u;
+#pragma unroll
+      for (int j = 0; j < SV_IN; ++j) {
+        const int64_t node = n0 + (tid + j * 256) / E;
+        if (live && node < a.N && z[j] >= 0 && z[j] < a.vocab) stg_ok |= 1u << j;
       }
     } else {
 #pragma unroll
@@ -149,7 +169,7 @@ __device__ __forceinline__ void schnet_node_body(const NodeArgs& a, int block, i
 #pragma unroll
       for (int j = 0; j < SV_IN; ++j) {
         const int i = tid + j * 256;
-        Xa[(i / E) * X_LD + (i % E)] = stg_in[j];
+        Xa[(i / E) * X_LD + (i % E)] = ((stg_ok >> j) & 1u) ? stg_in[j] : 0.0f;
       }
     } else {
 #pragma unroll
