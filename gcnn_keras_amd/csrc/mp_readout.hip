@@ -26,9 +26,32 @@ __global__ __launch_bounds__(256) void pool_mlp2_kernel(const float* __restrict_
   __shared__ float Ws[K * H];
   // 16-B global loads (all of a thread's requests in flight at once), swizzled scalar LDS stores
   constexpr int NV4 = K * H / 4 / 256;
+  const int lane = threadIdx.x & 63;
+  const int64_t wave_global = (static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x) >> 6;
+  const int64_t nwaves = (static_cast<int64_t>(gridDim.x) * blockDim.x) >> 6;
+  // the wave's first graph: row range requested before the weight matrix, its first 16 rows right behind it - the
+  // chain row_splits -> rows then runs beside the staging of W0 instead of behind it
+  constexpr bool PREFETCH = NK * NH != 4;   // K = H = 128: every register is taken (a spill = a scratch segment per launch)
+  constexpr int PRE = 16;
+  int64_t lo0 = 0, hi0 = 0;
+  if (wave_global < G) {
+    lo0 = splits[wave_global];
+    hi0 = splits[wave_global + 1];
+  }
   float4 stage[NV4];
 #pragma unroll
   for (int j = 0; j < NV4; ++j) stage[j] = reinterpret_cast<const float4*>(W0)[threadIdx.x + j * 256];
+  float v0[PREFETCH ? PRE : 1][NK];
+#pragma unroll
+  for (int u = 0; u < (PREFETCH ? PRE : 1); ++u)
+#pragma unroll
+    for (int q = 0; q < NK; ++q) v0[u][q] = 0.0f;
+  if (PREFETCH && hi0 > lo0) {   // wave-uniform
+#pragma unroll
+    for (int u = 0; u < PRE; ++u)
+#pragma unroll
+      for (int q = 0; q < NK; ++q) v0[u][q] = x[(lo0 + u < hi0 ? lo0 + u : hi0 - 1) * K + 64 * q + lane];
+  }
 #pragma unroll
   for (int j = 0; j < NV4; ++j) {
     const int i = 4 * (threadIdx.x + j * 256);
@@ -39,7 +62,6 @@ __global__ __launch_bounds__(256) void pool_mlp2_kernel(const float* __restrict_
     row[(c + 2) ^ (k & 31)] = stage[j].z;
     row[(c + 3) ^ (k & 31)] = stage[j].w;
   }
-  const int lane = threadIdx.x & 63;
   float b0v[NH], w1v[NH];
 #pragma unroll
   for (int h = 0; h < NH; ++h) {
@@ -48,19 +70,30 @@ __global__ __launch_bounds__(256) void pool_mlp2_kernel(const float* __restrict_
   }
   const float b1v = b1 ? b1[0] : 0.0f;
   __syncthreads();
-  const int64_t wave_global = (static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x) >> 6;
-  const int64_t nwaves = (static_cast<int64_t>(gridDim.x) * blockDim.x) >> 6;
   for (int64_t g = wave_global; g < G; g += nwaves) {
-    const int64_t lo = splits[g], hi = splits[g + 1];
+    const bool first = g == wave_global;
+    const int64_t lo = first ? lo0 : splits[g], hi = first ? hi0 : splits[g + 1];
     float pooled[NK];
 #pragma unroll
     for (int q = 0; q < NK; ++q) pooled[q] = 0.0f;
     for (int64_t base = lo; base < hi; base += 8) {   // eight rows in flight, added in node order
       float v[8][NK];
+      if (PREFETCH && first && base == lo) {
 #pragma unroll
-      for (int u = 0; u < 8; ++u)
+        for (int u = 0; u < 8; ++u)
 #pragma unroll
-        for (int q = 0; q < NK; ++q) v[u][q] = (base + u < hi) ? x[(base + u) * K + 64 * q + lane] : 0.0f;
+          for (int q = 0; q < NK; ++q) v[u][q] = v0[PREFETCH ? u : 0][q];
+      } else if (PREFETCH && first && base == lo + 8) {
+#pragma unroll
+        for (int u = 0; u < 8; ++u)
+#pragma unroll
+          for (int q = 0; q < NK; ++q) v[u][q] = v0[PREFETCH ? 8 + u : 0][q];
+      } else {
+#pragma unroll
+        for (int u = 0; u < 8; ++u)
+#pragma unroll
+          for (int q = 0; q < NK; ++q) v[u][q] = (base + u < hi) ? x[(base + u) * K + 64 * q + lane] : 0.0f;
+      }
 #pragma unroll
       for (int u = 0; u < 8; ++u)
 #pragma unroll
