@@ -16,8 +16,11 @@ import torch
 from . import _ffi
 
 
+_USE_COUNT = getattr(torch._C, "_storage_Use_Count", None)   # private torch API (also used by torch's CUDA-graph trees)
+
+
 def _holders(t):
-    return torch._C._storage_Use_Count(t.untyped_storage()._cdata), sys.getrefcount(t)
+    return _USE_COUNT(t.untyped_storage()._cdata), sys.getrefcount(t)
 
 
 class ResultRing:
@@ -30,6 +33,8 @@ class ResultRing:
         """``(tensors, graph)`` of a result set no caller holds, or ``None`` when all are held.  ``make() -> tuple of
         tensors`` allocates a set, ``capture(tensors) -> graph`` captures the slot's launches writing into it (both
         passed per call, so the ring holds no reference back to its slot)."""
+        if _USE_COUNT is None:      # no way to tell whether a view of a buffer is still alive: always copy
+            return None
         ring, entry = self._entries, None
         for k in range(len(ring)):
             cand = ring[(self._next + k) % len(ring)]
