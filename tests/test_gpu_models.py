@@ -513,3 +513,38 @@ def test_gcn_fused_route_padded_output():
         for g, n in enumerate(sizes):
             assert np.array_equal(padded[g, :n], ragged[ns[g]:ns[g + 1]])
             assert not padded[g, n:].any()
+
+
+@pytest.mark.parametrize("n,feats,with_edges", [(5, 7, False), (19, 3, True), (16, 16, True), (33, 70, True)])
+def test_gcn_fused_route_small_shapes(n, feats, with_edges):
+    """Corner shapes of the tile kernel: fewer than 16 nodes, fewer than 16 input features (only the ragged last k block
+    exists), an input width that is a multiple of 16 (no ragged block), a batch without any edge."""
+    from gcnn_keras_amd.literature import GCN
+    rng = np.random.default_rng(n + feats)
+    attrs = rng.normal(size=(n, feats)).astype(np.float32)
+    ns = np.array([0, n], np.int64)
+    if with_edges:
+        i = np.sort(rng.integers(0, n, size=3 * n))
+        idx = np.stack([i, rng.integers(0, n, size=3 * n)], 1).astype(np.int64)
+    else:
+        idx = np.zeros((0, 2), np.int64)
+    es = np.array([0, len(idx)], np.int64)
+    wts = rng.uniform(0.1, 1.0, size=(len(idx), 1)).astype(np.float32)
+    p = synth.gcn_params(seed=2, depth=2, in_features=feats, units=64, out_units=(16, 3), random_bias=True)
+    model = GCN.make_model(
+        inputs=[{"shape": (None, feats), "name": "node_attributes", "dtype": "float32", "ragged": True},
+                {"shape": (None, 1), "name": "edge_weights", "dtype": "float32", "ragged": True},
+                {"shape": (None, 2), "name": "edge_indices", "dtype": "int64", "ragged": True}],
+        gcn_args={"units": 64, "use_bias": True, "activation": "relu", "pooling_method": "sum"},
+        depth=2, output_embedding="node", output_to_tensor=False,
+        output_mlp={"use_bias": True, "units": [16, 3], "activation": ["relu", "softmax"]})
+    model.set_weights(list(p.values()))
+    ins = [_dev(attrs, ns), _dev(wts, es), _dev(idx, es)]
+    first = model(ins).values.cpu().numpy()
+    replayed = model(ins).values.cpu().numpy()
+    assert model.fused is not None and model.fused.last == "graph" and np.array_equal(first, replayed)
+
+    def oracle(dtype):
+        return ko.gcn_forward(ko.to_dtype(p, dtype), ko.R(attrs.astype(dtype), ns), ko.R(wts.astype(dtype), es),
+                              ko.R(idx, es), depth=2, output_mlp_act=("relu", "softmax")).values
+    _check(first, oracle(np.float32), oracle(np.float64))
