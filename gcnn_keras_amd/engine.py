@@ -123,11 +123,13 @@ class SchnetForward:
         if self.in_flight > 1:
             self._place_streams()
 
-    def _place_streams(self, draws=8, steps=150):
+    def _place_streams(self, draws=12, steps=150):
         """How well forwards in flight overlap depends on which hardware queues the streams land on (the ROCm runtime
         multiplexes streams onto a few queues; a stream sharing a queue with another serialises behind it: measured 48 vs
         64 us per step for different draws of four streams from torch's pool).  This draws the streams a few times,
-        measures ~100 forwards each and keeps the best draw.  Runs once per ``load_batch``, outside any timed region."""
+        measures ~150 forwards twice per draw - a draw is scored by the SLOWER of its two runs, so that one lucky run does
+        not select a placement that is slow most of the time - and keeps the best draw.  Runs once per ``load_batch``,
+        outside any timed region."""
         import time
 
         def rate():
@@ -142,7 +144,7 @@ class SchnetForward:
 
         best, best_streams = None, None
         for _ in range(draws):
-            t = rate()
+            t = max(rate(), rate())
             if best is None or t < best:
                 best, best_streams = t, list(self._streams)
             self._streams = [torch.cuda.Stream() for _ in range(self.in_flight)]
@@ -173,13 +175,19 @@ class SchnetForward:
         self.num_launches = _ffi.launch_count() - before
         return out
 
-    def replay(self, step=0):
+    def replay(self, step=0, restore_stream=True):
         """Fused mode: ``model(inputs[k])`` on stream ``k = step % in_flight`` (a re-bound batch: the model replays the
         slot's captured graph - one hipGraphLaunch - and copies the (G,1) result out); layers mode: same as ``forward``."""
         if self.mode == "fused":
             k = step % self.in_flight
-            with torch.cuda.stream(self._streams[k]):
-                return self.model(self._inputs[k])
+            if restore_stream:
+                with torch.cuda.stream(self._streams[k]):
+                    return self.model(self._inputs[k])
+            # a serving loop: set_stream instead of the context manager (two stream switches and a device guard per call,
+            # ~8 us of a ~30 us call); torch's current stream STAYS slot k's stream - the caller switches back when it is
+            # done (bench.py: torch.cuda.set_stream(default) before its closing barrier)
+            torch.cuda.set_stream(self._streams[k])
+            return self.model(self._inputs[k])
         return self.forward(step)
 
     @property

@@ -36,15 +36,21 @@ class ResultRing:
         if _USE_COUNT is None:      # no way to tell whether a view of a buffer is still alive: always copy
             return None
         ring, entry = self._entries, None
-        for k in range(len(ring)):
-            cand = ring[(self._next + k) % len(ring)]
-            if all(_holders(cand[0][i]) == cand[2][i] for i in range(len(cand[0]))):
-                entry = cand
-                self._next = (self._next + k + 1) % len(ring)
-                break
-        if entry is None:
-            if len(ring) >= self.size:
+        # The ring is filled to its size before a set is used a second time, and idle sets are then taken round robin:
+        # consecutive calls on one slot launch DIFFERENT graph executables.  Launching an executable whose previous launch
+        # is still running makes hipGraphLaunch wait for it on the host (its kernel arguments are still in use) - with one
+        # result set per slot the host could never be more than one forward ahead per stream, and while it waited for one
+        # stream's forward it fed none of the others.
+        if len(ring) >= self.size:
+            for k in range(len(ring)):
+                cand = ring[(self._next + k) % len(ring)]
+                if all(_holders(cand[0][i]) == cand[2][i] for i in range(len(cand[0]))):
+                    entry = cand
+                    self._next = (self._next + k + 1) % len(ring)
+                    break
+            if entry is None:
                 return None
+        else:
             entry = [tuple(make()), None, None]
             ring.append(entry)
             entry[2] = [_holders(entry[0][i]) for i in range(len(entry[0]))]
