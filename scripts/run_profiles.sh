@@ -11,6 +11,12 @@ rocprofv3 --kernel-trace --stats -d gpurun_out/prof5_sf -o sf -- python3 scripts
 rocprofv3 --kernel-trace --stats -d gpurun_out/prof5_pn_ef -o painn -- python3 scripts/profile_painn.py force 200 > gpurun_out/prof5_pn_ef.log 2>&1
 rocprofv3 --kernel-trace --stats -d gpurun_out/prof5_pn_f -o painn -- python3 scripts/profile_painn.py forward 200 > gpurun_out/prof5_pn_f.log 2>&1
 rocprofv3 --kernel-trace --stats -d gpurun_out/prof5_gcn -o gcn -- python3 scripts/profile_gcn.py 300 > gpurun_out/prof5_gcn.log 2>&1
+# condense on the box (the SQLite traces are 10-20 MB each; gpurun merges at most 64 MiB back) and drop the databases
+mkdir -p gpurun_out/stats
+for d in prof5_c2_1 prof5_c2_4 prof5_sf prof5_pn_ef prof5_pn_f prof5_gcn; do
+  db=$(find gpurun_out/$d -name "*_results.db" | head -1)
+  [ -n "$db" ] && python3 scripts/rocprof_db_stats.py $db gpurun_out/stats/$d.csv "$d" > /dev/null && rm -rf gpurun_out/$d
+done
 echo traces done
 if [ -n "$SKIP_PMC" ]; then exit 0; fi
 for c in FETCH_SIZE WRITE_SIZE; do
