@@ -63,7 +63,15 @@ if tag != "r01":   # round 2 on: kernel statistics come from rocprof_db_stats.py
                "fork configuration (depth 6, 25 bins), N=1344, M=20586"),
            pmc("pmc2_pn_fetch", "pmc2_pn_write", "scripts/profile_painn.py force: PaiNN energy+force, config 3, N=1344, "
                "M=20586")]
-    json.dump(res, open(os.path.join(ROOT, "profiles", "%s_pmc_hbm_traffic.json" % tag), "w"), indent=1)
+    res.append(pmc("pmc3_gcn_fetch", "pmc3_gcn_write", "config 5 (Cora-shaped graph, N=2708, M=13264, F=1433): "
+                   "scripts/profile_gcn.py, fused GCN forward"))
+    # passes that were not run this time keep their committed entry (same merge rule as scripts/merge_pmc.py)
+    out_path = os.path.join(ROOT, "profiles", "%s_pmc_hbm_traffic.json" % tag)
+    res = [e for e in res if e["kernels"]]
+    old = json.load(open(out_path)) if os.path.exists(out_path) else []
+    fresh = {e["label"] for e in res}
+    merged = sorted([e for e in old if e["label"] not in fresh] + res, key=lambda e: e["label"])
+    json.dump(merged, open(out_path, "w"), indent=1)
     print("profiles written")
     sys.exit(0)
 kernel_stats("prof_layers", "%s_layers_mode_kernel_stats.csv" % tag, "bench.py --mode layers (one engine call per Keras layer), config 2")
