@@ -173,7 +173,7 @@ class GcnTileDesc(ctypes.Structure):
                 ("h", c_void_p), ("ptr", c_void_p), ("perm", c_void_p), ("send", c_void_p), ("weight", c_void_p),
                 ("M", c_int64), ("agg_act", ctypes.c_int32), ("agg_alpha", c_float),
                 ("units_in", ctypes.c_int32), ("n_layers", ctypes.c_int32), ("layer", GcnLayerDesc * 3),
-                ("softmax_last", ctypes.c_int32), ("out", c_void_p)]
+                ("softmax_last", ctypes.c_int32), ("out", c_void_p), ("tile_start", c_void_p), ("n_tiles", c_int64)]
 
 
 _lib = None

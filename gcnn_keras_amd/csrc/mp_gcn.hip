@@ -62,6 +62,7 @@ struct GcnArgs {
   int64_t M;
   int agg_act;
   float agg_alpha;
+  const int32_t* tile_start;   // (ntiles + 1) first node of every tile, or null: tiles of 16 consecutive nodes
   // chain
   int n_layers;
   GcnLayer layer[3];
@@ -72,7 +73,7 @@ struct GcnArgs {
 // One Dense layer on the tile: Tout = act(Tin (16 x K) @ W (K x U) + b); the last layer of the chain writes global rows.
 __device__ __forceinline__ void dense_on_tile(const float* __restrict__ Tin, int K, const GcnLayer& L,
                                               float* __restrict__ Tout, float* __restrict__ gout, int64_t row0,
-                                              int64_t N, int wave, int lane) {
+                                              int rows, int wave, int lane) {
   const int U = L.units;
   const int g = lane >> 4, cc = lane & 15;
   const float* ap = Tin + cc * LD + g;
@@ -99,7 +100,7 @@ __device__ __forceinline__ void dense_on_tile(const float* __restrict__ Tin, int
       const int row = 4 * g + r;
       const float v = mp_apply_act(L.act, L.alpha, acc[r] + bias);
       if (gout) {
-        if (col_ok && row0 + row < N) gout[(row0 + row) * U + col] = v;
+        if (col_ok && row < rows) gout[(row0 + row) * U + col] = v;
       } else if (col_ok) {
         Tout[row * LD + col] = v;
       }
@@ -120,7 +121,11 @@ __global__ __launch_bounds__(256) void gcn_tile_kernel(GcnArgs a) {
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = tid >> 6;
-  const int64_t row0 = static_cast<int64_t>(blockIdx.x) * TR;
+  // aggregate launches may come with a tile table (at most 16 nodes AND a bounded number of edges per tile: a hub-heavy
+  // stretch of nodes is cut into several tiles instead of setting the launch's time alone)
+  const int64_t row0 = (MODE == 1 && a.tile_start) ? a.tile_start[blockIdx.x] : static_cast<int64_t>(blockIdx.x) * TR;
+  const int64_t row_end = (MODE == 1 && a.tile_start) ? a.tile_start[blockIdx.x + 1] : (row0 + TR < a.N ? row0 + TR : a.N);
+  const int rows = row_end - row0 < 0 ? 0 : (row_end - row0 > TR ? TR : static_cast<int>(row_end - row0));
 
   if constexpr (MODE == 0) {
     // ---- n = X W0 + b0 on the tile ----------------------------------------------------------------------------------
@@ -240,7 +245,7 @@ __global__ __launch_bounds__(256) void gcn_tile_kernel(GcnArgs a) {
     int* s_nid = reinterpret_cast<int*>(part + ROWS * UA + 2 * ECAP);
     const int grp = tid / LPR, gl = tid % LPR;
     if (tid <= TR) {
-      const int64_t n = row0 + tid < a.N ? row0 + tid : a.N;
+      const int64_t n = tid < rows ? row0 + tid : row_end;
       int64_t p = a.ptr[n];
       p = p < 0 ? 0 : (p > a.M ? a.M : p);
       seg[tid] = static_cast<int>(p);
@@ -366,14 +371,14 @@ __global__ __launch_bounds__(256) void gcn_tile_kernel(GcnArgs a) {
   int K = UA;
   for (int l = 0; l < a.n_layers; ++l) {
     const bool last = l + 1 == a.n_layers;
-    dense_on_tile(tin, K, a.layer[l], tout, (last && !a.softmax_last) ? a.out : nullptr, row0, a.N, wave, lane);
+    dense_on_tile(tin, K, a.layer[l], tout, (last && !a.softmax_last) ? a.out : nullptr, row0, rows, wave, lane);
     __syncthreads();
     K = a.layer[l].units;
     float* t = tin; tin = tout; tout = t;
   }
   if (a.softmax_last) {
     // Keras softmax over the last axis: exp(x - max) / sum, one thread per node row
-    if (tid < TR && row0 + tid < a.N) {
+    if (tid < rows) {
       const float* r = tin + tid * LD;
       float mx = -INFINITY;
       for (int c = 0; c < K; ++c) mx = fmaxf(mx, r[c]);
@@ -385,14 +390,14 @@ __global__ __launch_bounds__(256) void gcn_tile_kernel(GcnArgs a) {
   } else if (a.n_layers == 0) {
     for (int i = tid; i < TR * UA; i += 256) {
       const int r = i / UA, c = i % UA;
-      if (row0 + r < a.N) a.out[(row0 + r) * UA + c] = tin[r * LD + c];
+      if (r < rows) a.out[(row0 + r) * UA + c] = tin[r * LD + c];
     }
   }
 }
 
 template <int MODE>
-int launch_gcn(const GcnArgs& a, int ua, hipStream_t s) {
-  const unsigned grid = static_cast<unsigned>(mp::ceil_div(a.N, TR));
+int launch_gcn(const GcnArgs& a, int ua, int64_t ntiles, hipStream_t s) {
+  const unsigned grid = static_cast<unsigned>(ntiles);
   if (ua == 32) gcn_tile_kernel<MODE, 32><<<grid, 256, 0, s>>>(a);
   else if (ua == 64) gcn_tile_kernel<MODE, 64><<<grid, 256, 0, s>>>(a);
   else gcn_tile_kernel<MODE, 128><<<grid, 256, 0, s>>>(a);
@@ -426,12 +431,15 @@ extern "C" int mp_gcn_tile_f32(const mp_gcn_tile_desc* d, mpStream_t stream) {
   if (d->x != nullptr) {
     MP_REQUIRE(d->K >= 1 && d->W_in != nullptr, "mp_gcn_tile_f32: input mode needs K >= 1 and W_in");
     a.x = d->x; a.K = d->K; a.W_in = d->W_in; a.b_in = d->b_in;
-    return launch_gcn<0>(a, d->units_in, s);
+    return launch_gcn<0>(a, d->units_in, mp::ceil_div(a.N, TR), s);
   }
   MP_REQUIRE(d->h != nullptr && d->ptr != nullptr && d->M >= 0 && d->M < (int64_t{1} << 31) && (d->M == 0 || d->send != nullptr),
              "mp_gcn_tile_f32: aggregate mode needs h, ptr, send");
   MP_REQUIRE(d->agg_act >= MP_ACT_LINEAR && d->agg_act <= MP_ACT_LAST, "mp_gcn_tile_f32: unknown activation");
   a.h = d->h; a.ptr = d->ptr; a.perm = d->perm; a.send = d->send; a.weight = d->weight; a.M = d->M;
   a.agg_act = d->agg_act; a.agg_alpha = d->agg_alpha;
-  return launch_gcn<1>(a, d->units_in, s);
+  MP_REQUIRE(d->tile_start == nullptr || (d->n_tiles >= 1 && d->n_tiles < (int64_t{1} << 31)),
+             "mp_gcn_tile_f32: a tile table needs n_tiles >= 1");
+  a.tile_start = d->tile_start;
+  return launch_gcn<1>(a, d->units_in, d->tile_start ? d->n_tiles : mp::ceil_div(a.N, TR), s);
 }

@@ -490,6 +490,9 @@ typedef struct mp_gcn_tile_desc {
   mp_gcn_layer layer[3];
   int32_t softmax_last;
   float* out;
+  const int32_t* tile_start;  /* aggregate mode, nullable: (n_tiles + 1) first node of every tile - strictly increasing,   */
+  int64_t n_tiles;            /* tile_start[0] = 0, tile_start[n_tiles] = N, at most 16 nodes per tile (device array; lets */
+                              /* the caller cut hub-heavy node ranges into several tiles); NULL: 16 consecutive nodes      */
 } mp_gcn_tile_desc;
 int mp_gcn_tile_f32(const mp_gcn_tile_desc* desc_host, mpStream_t stream);
 
