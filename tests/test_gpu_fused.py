@@ -418,7 +418,7 @@ def test_forwards_in_flight_are_independent_and_identical():
     ref = ko.schnet_forward(p, ko.R(b["node_number"], b["node_splits"]), ko.R(b["node_coordinates"], b["node_splits"]),
                             ko.R(b["edge_indices"], b["edge_splits"]), depth=3)
     got = outs[0].cpu().numpy()
-    assert np.max(np.abs(got - ref)) <= 1e-5 * np.max(np.abs(ref))
+    assert_rows_close(got, ref, what="forwards in flight")
     multi.check_flags()
 
 
@@ -439,7 +439,7 @@ def test_direct_forward_launch_equals_graph_replay():
     assert torch.equal(direct, replayed)
     ref = ko.schnet_forward(p, ko.R(b["node_number"], b["node_splits"]), ko.R(b["node_coordinates"], b["node_splits"]),
                             ko.R(b["edge_indices"], b["edge_splits"]), depth=3)
-    assert np.max(np.abs(direct.cpu().numpy() - ref)) <= 1e-5 * np.max(np.abs(ref))
+    assert_rows_close(direct.cpu().numpy(), ref, what="direct forward launch")
     slot.check_flags()
 
 
