@@ -313,9 +313,11 @@ def run_config4(args, d, standalone=True):
     world = d.world
     inputs, bounds, total_edges = build_config4_shard(args.total_graphs, d.rank, world)
     n_nodes, n_edges, n_graphs = int(inputs[0].values.shape[0]), int(inputs[2].values.shape[0]), inputs[0].nrows()
-    params = synth.schnet_params(seed=7)
     model = Schnet.make_model(depth=DEPTH)
-    model.set_weights(list(params.values()))
+    if d.rank == 0:
+        model.set_weights(list(synth.schnet_params(seed=7).values()))
+    if world > 1:            # weights replicated by one broadcast at init (rank 0 holds the seeded set)
+        sharding.broadcast_weights(model, src=0)
     if model.fused is None or not model.fused.accepts(inputs):
         raise SystemExit("config 4 expects the fused route")
     gloo = world > 1 and d.backend == "gloo"

@@ -239,6 +239,13 @@ class GraphedModel:
     ``grad=True`` (default for an ``EnergyForceModel``) the capture includes the reverse pass that produces the forces.
     The graph is bound to the input buffers and to the batch's index structure: refresh feature / coordinate *values*
     in place (``inputs[i].values.copy_(...)``) between replays; a new edge list needs a new graph.
+
+    A captured fused route writes into the work buffers of the route's batch slot and reads the route's packed weight
+    images; the route's own slot table is least-recently-used with a small capacity, so this object holds the slot (and
+    the images) itself: binding more batches than ``max_slots``, or ``route.release()``, cannot free memory the graph
+    still uses.  ``__call__`` first lets the route refresh its derived weight layouts (``set_weights`` after the capture
+    is picked up: the images are re-filled in place) and raises if weight tensors were REPLACED by other objects - the
+    graph holds the old addresses, capture again.
     """
 
     def __init__(self, model, inputs, grad=None):
@@ -247,6 +254,7 @@ class GraphedModel:
         if grad is None:
             grad = hasattr(model, "energy_model")
         self.model, self.inputs, self.grad = model, inputs, bool(grad)
+        self._routes, self._pinned = [], []
         self.stream = torch.cuda.Stream()
         self.stream.wait_stream(torch.cuda.current_stream())
         # Models with a fused route replay their own HIP graph per bound batch; launching that graph into a capturing
@@ -268,13 +276,29 @@ class GraphedModel:
             with torch.set_grad_enabled(self.grad), torch.cuda.graph(self.graph, stream=self.stream):
                 self.output = model(inputs)
             torch.cuda.synchronize()
+            for r in routes:   # keep what the captured kernels address alive, whatever the route's slot table does later
+                for table in (getattr(r, "_slots", None), getattr(r, "_gslots", None)):
+                    if table:
+                        self._pinned.append(next(reversed(table.values())))      # most recently used = this capture's
+                self._pinned.extend(getattr(r, a, None) for a in ("_packed", "_images", "_grad_images", "_p"))
+                self._routes.append((r, self._weight_objects(r)))
         finally:
             for r, mode in zip(routes, saved):
                 r.mode = mode
             for m in auto:
                 m.auto_graph = True
 
+    @staticmethod
+    def _weight_objects(route):
+        key = getattr(route, "_wkey", None)
+        return None if key is None else tuple(k[:2] for k in key)    # (id, storage address) per weight tensor
+
     def __call__(self):
+        for r, objects in self._routes:
+            r._sync_weights()
+            if self._weight_objects(r) != objects:
+                raise _ffi.EngineError("GraphedModel: weight tensors of the model were replaced after the capture (the graph "
+                                       "holds the old addresses); build a new GraphedModel")
         self.graph.replay()
         return self.output
 
@@ -294,7 +318,7 @@ class GraphedModelPool:
         k = step % self.in_flight
         slot = self.slots[k]
         with torch.cuda.stream(slot.stream):
-            slot.graph.replay()
+            slot()
             ev = torch.cuda.Event()
             ev.record()
         self._events[k] = ev

@@ -15,6 +15,7 @@ import numpy as np
 import torch
 
 from . import _ffi
+from .layers.base import weight_epoch
 from .result_ring import ResultRing
 
 
@@ -485,7 +486,7 @@ class SchnetFusedRoute:
         self._gslots = {}           # batch slots of the energy + force pass (fused_schnet_force.FusedSchnetForce)
         self._p = None
         self._wkey = None
-        self._wlist, self._vsum, self._wcalls = None, 0, 0
+        self._wlist, self._vsum, self._wcalls, self._wepoch = None, 0, 0, -1
         self._packed = None
         self._grad_images = None    # transposed kernels / cfconv reverse images, built on the first force call
         self.single_state = True    # SchNet heads the route accepts end in one energy value per graph
@@ -511,9 +512,11 @@ class SchnetFusedRoute:
         # Fast path (every call): the version counters of the tensors seen at the last full check - in-place updates
         # (set_weights, an optimizer step) are what changes weights through this API, and they bump a counter.  The full
         # check (also notices a layer whose tensor OBJECT was replaced) walks the model: 24 us of host time per call
-        # against 6 us, so it runs on every 64th call; ``release()`` forces it.
+        # against 6 us, so it runs on every 64th call, whenever a weight tensor object was created or assigned anywhere
+        # (``layers.base.weight_epoch``), and after ``release()``.  Its key holds id, storage address and version: a
+        # ``tensor.data = ...`` swap (same object, same version) is seen there.
         wl = self._wlist
-        if wl is not None:
+        if wl is not None and self._wepoch == weight_epoch():
             self._wcalls += 1
             if self._wcalls & 63:
                 vs = 0
@@ -522,12 +525,13 @@ class SchnetFusedRoute:
                 if vs == self._vsum:
                     return
         p = self._tensors()
-        key = tuple((id(t), t._version) for t in p.values() if t is not None)
+        key = tuple((id(t), t.data_ptr(), t._version) for t in p.values() if t is not None)
         self._wlist = [t for t in p.values() if t is not None]
-        self._vsum = sum(k[1] for k in key)
+        self._vsum = sum(k[2] for k in key)
+        self._wepoch = weight_epoch()
         if key == self._wkey:
             return
-        moved = self._wkey is None or tuple(k[0] for k in key) != tuple(k[0] for k in self._wkey)
+        moved = self._wkey is None or tuple(k[:2] for k in key) != tuple(k[:2] for k in self._wkey)
         torch.cuda.synchronize()   # forwards in flight still read the old images
         if moved:                  # other tensors: every bound slot (descriptor, graph) points at the old ones
             self._slots.clear()

@@ -20,6 +20,7 @@ import numpy as np
 import torch
 
 from . import _ffi
+from .layers.base import weight_epoch
 from .result_ring import ResultRing
 
 _SUM = ("sum", "segment_sum", "reduce_sum")
@@ -375,7 +376,7 @@ class PainnFusedRoute:
         self.mode = "auto"       # auto: eager launches on first sight of a batch, graph replay afterwards | graph | eager
         self.copy_output = True
         self._slots, self._p, self._wkey, self._images = {}, None, None, None
-        self._wlist, self._vsum, self._wcalls = None, 0, 0
+        self._wlist, self._vsum, self._wcalls, self._wepoch = None, 0, 0, -1
         self.last = None
 
     @staticmethod
@@ -396,9 +397,11 @@ class PainnFusedRoute:
         # Fast path (every call): the version counters of the tensors seen at the last full check - in-place updates
         # (set_weights, an optimizer step) are what changes weights through this API, and they bump a counter.  The full
         # check (also notices a layer whose tensor OBJECT was replaced) walks the model: 24 us of host time per call
-        # against 6 us, so it runs on every 64th call; ``release()`` forces it.
+        # against 6 us, so it runs on every 64th call, whenever a weight tensor object was created or assigned anywhere
+        # (``layers.base.weight_epoch``), and after ``release()``.  Its key holds id, storage address and version: a
+        # ``tensor.data = ...`` swap (same object, same version) is seen there.
         wl = self._wlist
-        if wl is not None:
+        if wl is not None and self._wepoch == weight_epoch():
             self._wcalls += 1
             if self._wcalls & 63:
                 vs = 0
@@ -407,12 +410,13 @@ class PainnFusedRoute:
                 if vs == self._vsum:
                     return
         p = self._tensors()
-        key = tuple((id(t), t._version) for t in p.values() if t is not None)
+        key = tuple((id(t), t.data_ptr(), t._version) for t in p.values() if t is not None)
         self._wlist = [t for t in p.values() if t is not None]
-        self._vsum = sum(k[1] for k in key)
+        self._vsum = sum(k[2] for k in key)
+        self._wepoch = weight_epoch()
         if key == self._wkey:
             return
-        moved = self._wkey is None or tuple(k[0] for k in key) != tuple(k[0] for k in self._wkey)
+        moved = self._wkey is None or tuple(k[:2] for k in key) != tuple(k[:2] for k in self._wkey)
         torch.cuda.synchronize()
         if moved:
             self._slots.clear()

@@ -36,8 +36,30 @@ def _camel_to_snake(name):
     return "".join(out)
 
 
+_weight_epoch = [0]
+
+
+def weight_epoch():
+    """Counts weight-tensor OBJECT changes anywhere (``add_weight``, ``layer.kernel = other_tensor``): the fused routes
+    compare it on every call, so a replaced tensor is seen at once.  In-place updates are seen through the tensors' version
+    counters; only ``tensor.data = ...`` (same object, same version, other storage) waits for a route's periodic full walk."""
+    return _weight_epoch[0]
+
+
 class Layer:
     """Just enough of ``ks.layers.Layer``: naming, lazy build, weights, ``get_config``."""
+
+    def __setattr__(self, key, value):
+        if torch.is_tensor(value):
+            old = self.__dict__.get(key)
+            if torch.is_tensor(old) and old is not value:
+                ws = self.__dict__.get("_weights")
+                if ws is not None:            # the attribute names a weight: keep the weight list on the new object
+                    for i, (n, t) in enumerate(ws):
+                        if t is old:
+                            ws[i] = (n, value)
+            _weight_epoch[0] += 1
+        object.__setattr__(self, key, value)
 
     def __init__(self, name=None, trainable=True, dtype="float32", **kwargs):
         if kwargs:
@@ -81,6 +103,7 @@ class Layer:
             raise ValueError("Unsupported initializer %r" % (initializer,))
         t = torch.from_numpy(np.array(arr, dtype=np.float32, order="C")).to(device)   # C order, 0-d stays 0-d
         self._weights.append((name, t))
+        _weight_epoch[0] += 1
         return t
 
     def sublayers(self):

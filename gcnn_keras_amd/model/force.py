@@ -61,7 +61,7 @@ class EnergyForceModel:
         """inputs: list for the energy model; the ragged coordinates ``(batch, [N], 3)`` sit at ``coordinate_input``.
         Returns ``{"energy", "force"}`` or ``(outputs, force)`` like the reference (force.py:195-201)."""
         x = inputs[self.coordinate_input]
-        fused = self._fused_energy_force(inputs)
+        fused = self._fused_energy_force(inputs, kwargs)
         if fused is not None:
             return fused
         inputs_energy = list(inputs)
@@ -115,12 +115,15 @@ class EnergyForceModel:
 
     predict = __call__
 
-    def _fused_energy_force(self, inputs):
+    def _fused_energy_force(self, inputs, kwargs=None):
         """Energy models that bring a fused reverse pass (``model.fused.energy_force``: PAiNN, gcnn_keras_amd/fused_painn.py)
         return energy and -dE/dx from one captured HIP graph instead of the tape + layer-by-layer reverse pass below.
         Taken when the wrapper is in its plain form: coordinates at input 1, one energy state, the energy model returning
-        the energy alone."""
+        the energy alone, and no call argument that the energy model itself would have to see (``fused=False`` forces the
+        layer path there, ``training=True`` belongs to the layer path: both take the tape here as well)."""
         route = getattr(self.energy_model, "fused", None)
+        if kwargs and any(not (k == "training" and not v) for k, v in kwargs.items()):
+            return None
         if (route is None or not hasattr(route, "energy_force") or self.fused is False or self.coordinate_input != 1
                 or self.esp_input is not None or len(inputs) != 3 or not getattr(route, "single_state", False)
                 or not route.accepts(list(inputs), with_forces=True)):

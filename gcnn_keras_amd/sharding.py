@@ -48,20 +48,74 @@ def shard_batch(batch, rank, world_size):
     return take_shard(batch, lo, hi), bounds
 
 
-def all_gather_predictions(local_pred, bounds, group=None):
+def all_gather_predictions(local_pred, bounds, group=None, empty_row=None):
     """Gather per-graph predictions of every rank into the original graph order.
 
-    ``local_pred``: torch tensor ``(hi - lo, L)`` on this rank's device.  Shards differ in size, so each rank pads to
-    the largest shard (equal chunks = one ``all_gather_into_tensor``), then the padding is dropped."""
+    ``local_pred``: torch tensor ``(rows, L)`` on this rank's device.  The row count of rank r's part is taken from
+    ``bounds`` (``hi - lo`` graphs), not from the tensor: shards differ in size, so every rank pads to the largest shard
+    (equal chunks = ONE ``all_gather_into_tensor``) and the padding is dropped afterwards.
+
+    A shard that ends in graphs without nodes returns fewer rows than it has graphs (``PoolingNodes`` follows
+    ``tf.math.segment_*``, which sizes its output by the last non-empty segment, kgcnn/layers/pooling.py:215-218).  In the
+    unsharded forward such graphs are gaps inside the batch - the segment op fills them with zeros and the output MLP maps
+    that to a constant row - unless they end the whole batch, where they are dropped.  The gather reproduces both: rows a
+    shard did not return are ``empty_row`` (the model's prediction for a graph without nodes, ``(L,)``; NaN when not given,
+    so a missing value is never silently a number), and rows missing at the end of the LAST shard are dropped."""
     import torch
     import torch.distributed as dist
     world = dist.get_world_size(group)
+    rank = dist.get_rank(group)
+    if len(bounds) != world:
+        raise ValueError("all_gather_predictions: %d shard bounds for %d ranks" % (len(bounds), world))
     sizes = [hi - lo for lo, hi in bounds]
-    width = int(local_pred.shape[1]) if local_pred.dim() > 1 else 1
+    if local_pred.dim() == 1:
+        local_pred = local_pred.unsqueeze(-1)
+    rows, width = int(local_pred.shape[0]), int(local_pred.shape[1])
+    if rows > sizes[rank]:
+        raise ValueError("all_gather_predictions: rank %d returned %d rows for %d graphs" % (rank, rows, sizes[rank]))
     chunk = max(sizes)
-    send = torch.zeros((chunk, width), dtype=local_pred.dtype, device=local_pred.device)
-    send[:local_pred.shape[0]] = local_pred.reshape(-1, width)
-    recv = torch.empty((world * chunk, width), dtype=local_pred.dtype, device=local_pred.device)
+    # one extra column carries the number of rows the rank really returned (rides in the same collective)
+    send = torch.zeros((chunk + 1, width), dtype=local_pred.dtype, device=local_pred.device)
+    send[:rows] = local_pred
+    send[chunk, 0] = rows
+    recv = torch.empty((world * (chunk + 1), width), dtype=local_pred.dtype, device=local_pred.device)
     dist.all_gather_into_tensor(recv, send, group=group)
-    parts = [recv[r * chunk:r * chunk + sizes[r]] for r in range(world)]
+    recv = recv.reshape(world, chunk + 1, width)
+    returned = [int(v) for v in recv[:, chunk, 0].round().to(torch.int64).cpu().tolist()]
+    parts = []
+    for r in range(world):
+        part = recv[r, :sizes[r]]
+        if returned[r] < sizes[r]:
+            if r == world - 1:
+                part = part[:returned[r]]                      # trailing empty graphs of the batch: dropped, as unsharded
+            else:
+                part = part.clone()
+                part[returned[r]:] = float("nan") if empty_row is None else torch.as_tensor(
+                    empty_row, dtype=part.dtype, device=part.device).reshape(1, width)
+        parts.append(part)
     return torch.cat(parts, dim=0)
+
+
+def broadcast_weights(model, src=0, group=None):
+    """Replicate the model's weights from rank ``src`` (one broadcast at init; ~1 MB for SchNet depth 3):
+    all weight tensors travel as ONE flat buffer - one collective, latency-bound - and are written back in place, so the
+    fused routes see moved version counters and refresh their packed images."""
+    import torch
+    import torch.distributed as dist
+    tensors = [t for _, t in model.weights]
+    if not tensors:
+        return 0
+    flat = torch.cat([t.detach().reshape(-1).to(torch.float32) for t in tensors])
+    if flat.is_cuda and dist.get_backend(group) == "gloo":     # CPU rehearsal of a GPU run: stage through the host
+        host = flat.cpu()
+        dist.broadcast(host, src=src, group=group)
+        flat = host.to(flat.device)
+    else:
+        dist.broadcast(flat, src=src, group=group)
+    at = 0
+    with torch.no_grad():
+        for t in tensors:
+            n = t.numel()
+            t.copy_(flat[at:at + n].reshape(t.shape))
+            at += n
+    return int(flat.numel())

@@ -7,6 +7,7 @@ import torch
 
 from gcnn_keras_amd import synth
 from oracle import kgcnn_oracle as ko
+from parity import assert_rows_close
 
 pytestmark = pytest.mark.gpu
 
@@ -233,6 +234,46 @@ def test_graphed_model_pool_overlaps_batches_of_a_layer_path_model():
     torch.cuda.synchronize()
     t_one = (time.perf_counter() - t0) / 60
     print("PaiNN forward (8 graphs): one graph at a time %.0f us, three in flight %.0f us per forward" % (t_one * 1e6, t_pool * 1e6))
+
+
+def test_graphed_models_outlive_the_routes_slot_table_and_follow_weight_updates():
+    """A GraphedModel of a fused-route model keeps the batch slot its graph addresses alive: ten captured batches on a
+    route with max_slots = 8 (the first captures are evicted from the route's table), then ``route.release()`` - every
+    graph still replays the oracle's numbers.  ``set_weights`` after the capture is picked up by the replay (derived
+    weight images re-filled in place); replacing a weight tensor object makes the replay raise."""
+    from gcnn_keras_amd import _ffi
+    from gcnn_keras_amd.engine import GraphedModel
+    from gcnn_keras_amd.literature import Schnet
+    p = synth.schnet_params(seed=7, depth=2, random_bias=True)
+    model = Schnet.make_model(depth=2)
+    model.set_weights(list(p.values()))
+    assert model.fused is not None and model.fused.max_slots == 8
+    batches = [synth.qm9_like_batch(num_graphs=4, seed=60 + k) for k in range(10)]
+    inputs = [[_dev(b["node_number"], b["node_splits"]), _dev(b["node_coordinates"], b["node_splits"]),
+               _dev(b["edge_indices"], b["edge_splits"])] for b in batches]
+
+    def oracle(pp, b):
+        return ko.schnet_forward(pp, ko.R(b["node_number"], b["node_splits"]), ko.R(b["node_coordinates"], b["node_splits"]),
+                                 ko.R(b["edge_indices"], b["edge_splits"]), depth=2)
+
+    graphed = [GraphedModel(model, x) for x in inputs]
+    assert len(model.fused._slots) <= 8
+    junk = [torch.full((1 << 20,), float("nan"), device="cuda") for _ in range(8)]   # re-use freed blocks, if any were freed
+    for g, b in zip(graphed, batches):
+        assert_rows_close(g().cpu().numpy(), oracle(p, b), what="graphed batch beyond max_slots")
+    model.fused.release()
+    junk += [torch.full((1 << 20,), float("nan"), device="cuda") for _ in range(8)]
+    for g, b in zip(graphed, batches):
+        assert_rows_close(g().cpu().numpy(), oracle(p, b), what="graphed batch after release()")
+    p2 = synth.schnet_params(seed=11, depth=2, random_bias=True)
+    model.set_weights(list(p2.values()))
+    for g, b in zip(graphed[:3], batches[:3]):
+        assert_rows_close(g().cpu().numpy(), oracle(p2, b), what="graphed batch after set_weights")
+    lay = next(l for l in model.layers if torch.is_tensor(getattr(l, "kernel", None)))
+    lay.kernel = lay.kernel.clone()
+    with pytest.raises(_ffi.EngineError):
+        graphed[0]()
+    del junk
 
 
 @pytest.mark.parametrize("v2,concat", [(False, False), (False, True), (True, False)])

@@ -68,6 +68,9 @@ def test_hip_forward_all_gather_under_rccl_world_size_1():
     dist.init_process_group("nccl", init_method="tcp://127.0.0.1:%d" % _free_port(), rank=0, world_size=1,
                             device_id=torch.device("cuda", torch.cuda.current_device()))
     try:
+        before = model.get_weights()
+        sent = sharding.broadcast_weights(model, src=0)            # one flat ncclBroadcast, written back in place
+        assert sent == sum(w.size for w in before) and all(np.array_equal(a, c) for a, c in zip(before, model.get_weights()))
         pred = model(mol_inputs(shard))
         full = sharding.all_gather_predictions(pred, bounds)       # all_gather_into_tensor over RCCL
         torch.cuda.synchronize()

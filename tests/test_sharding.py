@@ -77,3 +77,85 @@ def test_sharded_forward_matches_whole_batch_gloo():
                             ko.R(b["edge_indices"], b["edge_splits"]), depth=3)
     assert got.shape == ref.shape == (9, 1)
     assert np.max(np.abs(got - ref)) <= 1e-6 * np.max(np.abs(ref))   # graphs are independent: same rows, same math
+
+
+def _worker_config4_like(rank, world, port, queue):
+    """bench.py's config-4 step in miniature: the same generator (``synth.qm9_like_nodes``), shard bounds by edge count,
+    one forward per shard (played by the oracle), weights broadcast from rank 0, one all-gather - on a batch in which
+    shard 0 ENDS in graphs without nodes and the batch itself ends in one."""
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    b, bounds = _config4_like_batch()
+    lo, hi = bounds[rank]
+    shard = sharding.take_shard(b, lo, hi)
+
+    class Holder:            # the weights as a model would hold them; rank 1 starts from OTHER values
+        def __init__(self, seed):
+            self.p = synth.schnet_params(seed=seed, random_bias=True)
+            self.weights = [(k, torch.from_numpy(v.copy())) for k, v in self.p.items()]
+
+    model = Holder(7 if rank == 0 else 99)
+    sent = sharding.broadcast_weights(model, src=0)
+    p = {k: t.numpy() for k, t in model.weights}
+    pred = ko.schnet_forward(p, ko.R(shard["node_number"], shard["node_splits"]),
+                             ko.R(shard["node_coordinates"], shard["node_splits"]),
+                             ko.R(shard["edge_indices"], shard["edge_splits"]), depth=3)
+    empty = _empty_graph_row(p)
+    full = sharding.all_gather_predictions(torch.from_numpy(pred), bounds, empty_row=empty)
+    loud = sharding.all_gather_predictions(torch.from_numpy(pred), bounds)
+    queue.put((rank, full.numpy(), loud.numpy(), pred.shape[0], hi - lo, sent,
+               float(np.abs(p["dense0/kernel"] - synth.schnet_params(seed=7, random_bias=True)["dense0/kernel"]).max())))
+    dist.destroy_process_group()
+
+
+def _config4_like_batch(graphs=200):
+    nodes = synth.qm9_like_nodes(graphs, seed=3456)
+    ns = nodes["node_splits"]
+    es = [synth.radius_graph(nodes["node_coordinates"][ns[g]:ns[g + 1]], 4.0, 30) for g in range(graphs)]
+    b = dict(nodes, edge_indices=np.concatenate(es).astype(np.int64),
+             edge_splits=np.concatenate([[0], np.cumsum([len(e) for e in es])]).astype(np.int64))
+    cut = sharding.shard_bounds_by_edges(b["edge_splits"], 2)[0][1]
+    # two graphs without nodes where shard 0 will end, one at the end of the batch
+    def insert(arr, at, count):
+        return np.concatenate([arr[:at + 1], np.repeat(arr[at], count), arr[at + 1:]])
+    b["node_splits"] = insert(insert(b["node_splits"], graphs, 1), cut, 2)
+    b["edge_splits"] = insert(insert(b["edge_splits"], graphs, 1), cut, 2)
+    # the edge-count cut of the 200 molecules, with the two empty graphs closing shard 0 (the balance rule itself would
+    # hand them to shard 1, where they are gaps in front of its first molecule)
+    return b, [(0, cut + 2), (cut + 2, graphs + 3)]
+
+
+def _empty_graph_row(p):
+    """The model's prediction for a graph without nodes: pooled zeros through the output MLP (Schnet.py:140-146)."""
+    zero = np.zeros((1, p["output_mlp/0/kernel"].shape[0]), np.float32)
+    return ko.mlp(zero, [(p["output_mlp/0/kernel"], p["output_mlp/0/bias"], "kgcnn>shifted_softplus"),
+                         (p["output_mlp/1/kernel"], p["output_mlp/1/bias"], "linear")])[0]
+
+
+def test_config4_step_with_broadcast_and_empty_trailing_graphs_gloo():
+    world = 2
+    ctx = mp.get_context("spawn")
+    queue = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_config4_like, args=(r, world, port, queue)) for r in range(world)]
+    for pr in procs:
+        pr.start()
+    res = dict((r[0], r[1:]) for r in (queue.get(timeout=300), queue.get(timeout=300)))
+    for pr in procs:
+        pr.join(timeout=60)
+        assert pr.exitcode == 0
+    b, bounds = _config4_like_batch()
+    p = synth.schnet_params(seed=7, random_bias=True)
+    ref = ko.schnet_forward(p, ko.R(b["node_number"], b["node_splits"]), ko.R(b["node_coordinates"], b["node_splits"]),
+                            ko.R(b["edge_indices"], b["edge_splits"]), depth=3)
+    assert ref.shape == (202, 1)                      # 203 graphs, the trailing empty one dropped (tf.math.segment_sum)
+    for rank in range(world):
+        full, loud, rows, graphs, sent, wdiff = res[rank]
+        assert wdiff == 0.0 and sent == sum(v.size for v in p.values())      # rank 1 now holds rank 0's weights
+        assert rows < graphs                                                    # both shards end in empty graphs
+        assert full.shape == ref.shape
+        assert np.max(np.abs(full - ref)) <= 1e-6 * np.max(np.abs(ref))
+        # without empty_row the rows a shard did not return are NaN, never a silent number
+        lo, hi = bounds[0]
+        assert np.isnan(loud[hi - 2:hi]).all() and np.isfinite(np.delete(loud, [hi - 2, hi - 1], axis=0)).all()
