@@ -57,8 +57,9 @@ def schnet_flops(n, m, g, f=128, b=20, d=3):
             + g * 2 * (64 * 64 + 64))
 
 
-def _timed(run, budget_s, max_runs=200):
-    run()  # warm-up
+def _timed(run, budget_s, max_runs=200, warmup=1):
+    for _ in range(warmup):
+        run()
     times = []
     t_end = time.perf_counter() + budget_s
     while time.perf_counter() < t_end and len(times) < max_runs:
@@ -66,6 +67,22 @@ def _timed(run, budget_s, max_runs=200):
         run()
         times.append(time.perf_counter() - t0)
     return float(np.median(times)), len(times)
+
+
+def _protocol(run, forwards=50, warmup=5, cap_s=20.0):
+    """warm-up 5, then 50 forwards of the same batch; median and p10 / p90 of the per-forward
+    times.  ``cap_s`` bounds the sample on a slow host (the count actually run is reported)."""
+    for _ in range(warmup):
+        run()
+    times = []
+    t_end = time.perf_counter() + cap_s
+    while len(times) < forwards and (time.perf_counter() < t_end or len(times) < 5):
+        t0 = time.perf_counter()
+        run()
+        times.append(time.perf_counter() - t0)
+    t = np.asarray(times)
+    return {"median": float(np.median(t)), "p10": float(np.percentile(t, 10)), "p90": float(np.percentile(t, 90)),
+            "forwards": int(t.size)}
 
 
 def _best_threads(run, set_threads, candidates, probe_s=1.0):
@@ -81,10 +98,11 @@ def _best_threads(run, set_threads, candidates, probe_s=1.0):
     return best[1]
 
 
-def cpu_baseline(batch, params, depth, budget_s=6.0):
+def cpu_baseline(batch, params, depth):
     """CPU restatements of the reference's unfused op sequence on this host's cores: (i) the
     C/OpenMP port oracle/mp_oracle.c, (ii) torch-CPU (index_select / index_add_ / addmm), each at the thread count that
-    is fastest on this host, ~budget_s of timed forwards each.  ``value`` is the faster of the two; both are listed."""
+    is fastest on this host (a one-second probe per candidate), then the protocol's sample: warm-up 5 + 50 forwards of the
+    same batch, median with p10 / p90.  ``value`` is the faster of the two medians; both legs are listed."""
     from oracle import c_oracle, torch_oracle
     import torch
     m = int(batch["edge_splits"][-1])
@@ -97,21 +115,23 @@ def cpu_baseline(batch, params, depth, budget_s=6.0):
                                               batch["edge_indices"], batch["node_splits"], batch["edge_splits"],
                                               depth=depth)
         threads = _best_threads(run, c_oracle.set_num_threads, candidates)
-        med, runs = _timed(run, budget_s)
-        legs["c_openmp"] = {"value": m / med, "median_ms": med * 1e3, "forwards": runs, "threads": threads,
+        st = _protocol(run)
+        legs["c_openmp"] = {"value": m / st["median"], "median_ms": st["median"] * 1e3, "p10_ms": st["p10"] * 1e3,
+                            "p90_ms": st["p90"] * 1e3, "forwards": st["forwards"], "threads": threads,
                             "what": "C/OpenMP port oracle/mp_oracle.c"}
     tp, tb = torch_oracle.to_torch(params), torch_oracle.prepare(batch)
     run = lambda: torch_oracle.schnet_forward(tp, tb, depth=depth)
     threads = _best_threads(run, torch.set_num_threads, candidates)
-    med, runs = _timed(run, budget_s)
-    legs["torch_cpu"] = {"value": m / med, "median_ms": med * 1e3, "forwards": runs, "threads": threads,
+    st = _protocol(run)
+    legs["torch_cpu"] = {"value": m / st["median"], "median_ms": st["median"] * 1e3, "p10_ms": st["p10"] * 1e3,
+                         "p90_ms": st["p90"] * 1e3, "forwards": st["forwards"], "threads": threads,
                          "what": "torch-CPU restatement oracle/torch_oracle.py (index_select / index_add_ / addmm)"}
     best = max(legs, key=lambda k: legs[k]["value"])
     return {"value": legs[best]["value"], "unit": "edges/s", "cores": int(legs[best]["threads"]), "kind": "port",
-            "sample": "%d forwards of the same %d-graph batch (median %.1f ms) with the %s on %d threads (fastest of %s "
-                      "threads; host has %d logical cores)" % (legs[best]["forwards"], g, legs[best]["median_ms"],
-                                                               legs[best]["what"], legs[best]["threads"], candidates,
-                                                               ncpu),
+            "sample": "warm-up 5 + %d forwards of the same %d-graph batch (median %.1f ms, p10 %.1f, p90 %.1f) with the %s "
+                      "on %d threads (fastest of %s threads in a 1-s probe each; host has %d logical cores)" % (
+                          legs[best]["forwards"], g, legs[best]["median_ms"], legs[best]["p10_ms"], legs[best]["p90_ms"],
+                          legs[best]["what"], legs[best]["threads"], candidates, ncpu),
             "legs": legs}
 
 

@@ -16,6 +16,7 @@ LIB_PATH = os.path.join(_HERE, "csrc", "libmpengine.so")
 MP_OK, MP_EINVAL, MP_EINDEX, MP_EHIP, MP_ENOTSUP = 0, -1, -2, -3, -4
 MP_SUM, MP_MEAN, MP_MAX, MP_MIN = 0, 1, 2, 3
 MP_ADD, MP_SUB, MP_MUL = 0, 1, 2
+MP_PAINN_FILTER_IMAGE_BYTES = 73728   # include/mpengine.h
 MP_FLAG_OOB, MP_FLAG_UNSORTED_COL0, MP_FLAG_UNSORTED_COL1 = 1, 2, 4
 
 ACTIVATION_CODES = {
@@ -88,6 +89,9 @@ _SIGNATURES = {
     "mp_painn_stage0_f32": [P, c_int, c_int64, P, c_int, c_float, P, P, P, c_int64, P, P, c_int64, P, P, c_int, c_float, c_int,
                             c_float, P, P, P, P, P, P, P, P, P, P],
     "mp_painn_message_f32": [P, P, c_int64, P, c_int, P, P, P, P, P, P, P, c_int64, P, P, P, P],
+    "mp_painn_filter_pack_f32": [P, P, c_int, P, P],
+    "mp_painn_message_tiles_lds_bytes": [c_int, c_int, c_int, c_int, P],
+    "mp_painn_message_tiles_f32": [P, P, c_int64, P, c_int, P, P, P, P, P, c_int64, P, c_int, c_int, c_int, P, P, P, P],
     "mp_painn_message_bwd_f32": [P, P, c_int64, P, P, c_int, P, P, P, P, P, P, P, P, c_int64, P, P, P, P, P, P, c_int, P],
     "mp_painn_update_pre_f32": [P, P, c_int64, P, P, P],
     "mp_painn_update_fused_f32": [P, P, P, c_int64, P, P, c_int, c_float, P, P, P, P, P, P, P, P, P],

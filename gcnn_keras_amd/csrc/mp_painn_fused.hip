@@ -19,6 +19,9 @@
 //
 // All kernels are HBM/L2-bound streaming or gather kernels except the GEMMs; the per-edge filter (K = B = 20) is far too
 // thin for MFMA tiles and runs on the VALU as packed FP32 FMAs with the lane's weight columns in registers.
+#include <cstdlib>
+#include <mutex>
+
 #include "mp_common.h"
 #include "mp_edge_prepare.h"
 
@@ -327,6 +330,515 @@ __global__ __launch_bounds__(256) void painn_message_kernel(PainnMsgArgs a) {
     a.ds[static_cast<int64_t>(n) * F + f0] = ds;
 #pragma unroll
     for (int k = 0; k < 3; ++k) a.dv[(static_cast<int64_t>(n) * 3 + k) * F + f0] = dv[k];
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------- message, MFMA
+// The same message step with the per-edge filter  w_e = rbf_e Ww + bw  (K = B + 1 <= 32 -> 3F = 384 columns, 15 kflop per
+// edge: 85 % of the step's arithmetic) on the matrix pipe instead of 60 FMAs per lane and edge on the VALU.  FP32-exact
+// as in csrc/mp_cfconv.hip: both operands are split into three bf16 pieces (8 + 8 + 8 mantissa bits, every difference exact
+// in FP32) and the six leading cross products run on v_mfma_f32_32x32x16_bf16 with FP32 accumulation (the dropped products
+// are below 2^-24 of |a||b|, the rounding of one FP32 product).
+//
+// Work split: a workgroup of four waves serves a PAIR of receiving nodes, wave q the feature quarter 32 q .. 32 q + 31 of
+// all three filter parts.  One MFMA tile = 32 edge rows x 32 features: the accumulator leaves rows {0-3, 8-11, 16-19,
+// 24-27} in lanes 0-31 and rows {4-7, 12-15, ...} in lanes 32-63, sixteen rows per lane - so lane half h is given the
+// edges of receiver 2 pair + h (row m of the A operand = edge (m & 3) + 4 (m >> 3) of the half (m >> 2) & 1), and each half
+// walks ITS receiver's edges in register order = edge order (the order of tf.math.segment_sum after the stable sort:
+// deterministic, no atomics, no cross-lane step at all).  A lane = one feature of one receiver: the sender rows s_j, v_j
+// arrive as 128-B pieces (32 lanes x 4 B), eight edges in flight per lane.  Rows beyond a receiver's edge count carry a
+// zero A row (bias slot included), so their filter - and message - is exactly 0; their loads re-read a valid edge.
+// The weights Ww | bw are split into the wave's 18 B-operand registers x 4 once per wave (workgroups are persistent over
+// pairs); the basis rows are split per tile.
+using bf16x8 = __attribute__((ext_vector_type(8))) __bf16;
+using floatx16 = __attribute__((ext_vector_type(16))) float;
+
+__device__ __forceinline__ void split3_into(float x, bf16x8& hi, bf16x8& mid, bf16x8& lo, int i) {
+  const __bf16 p0 = static_cast<__bf16>(x);
+  const float r1 = x - static_cast<float>(p0);
+  const __bf16 p1 = static_cast<__bf16>(r1);
+  const float r2 = r1 - static_cast<float>(p1);
+  hi[i] = p0;
+  mid[i] = p1;
+  lo[i] = static_cast<__bf16>(r2);
+}
+
+// acc += A B as the six leading products of the three-piece split, smallest first
+__device__ __forceinline__ floatx16 mfma_bf16x3(const bf16x8 (&qa)[3], const bf16x8 (&qb)[3], floatx16 acc) {
+  acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qa[2], qb[0], acc, 0, 0, 0);
+  acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qa[0], qb[2], acc, 0, 0, 0);
+  acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qa[1], qb[1], acc, 0, 0, 0);
+  acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qa[1], qb[0], acc, 0, 0, 0);
+  acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qa[0], qb[1], acc, 0, 0, 0);
+  acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qa[0], qb[0], acc, 0, 0, 0);
+  return acc;
+}
+
+// B operands of the filter GEMM for this lane: column f0 of part p, k = 16 ks + 8 (lane >> 5) + i; row B is the bias.
+// Every load is unconditional from a clamped address and masked afterwards (a conditional load costs a branch and a
+// full wait per load in hipcc's output).
+template <int BT>
+__device__ __forceinline__ void painn_filter_operands(const float* __restrict__ Ww, const float* __restrict__ bw, int B,
+                                                      int f0, int hh, bf16x8 (&wb)[3][2][3]) {
+  const float* bwp = bw != nullptr ? bw : Ww;       // any readable address; masked by has_b
+  const float has_b = bw != nullptr ? 1.0f : 0.0f;
+#pragma unroll
+  for (int p = 0; p < 3; ++p) {
+    const float bias = bwp[p * F + f0] * has_b;
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        const int k = 16 * ks + 8 * hh + i;
+        if (BT > 0 && 16 * ks + i > BT) {             // beyond the bias slot for both lane halves: compile-time zero
+          split3_into(0.0f, wb[p][ks][0], wb[p][ks][1], wb[p][ks][2], i);
+          continue;
+        }
+        const int kc = k < B ? k : B - 1;
+        const float w = Ww[static_cast<int64_t>(kc) * 3 * F + p * F + f0];
+        // masks, not selects: a select lets the compiler sink the load into a branch
+        const float x = w * (k < B ? 1.0f : 0.0f) + bias * (k == B ? 1.0f : 0.0f);
+        split3_into(x, wb[p][ks][0], wb[p][ks][1], wb[p][ks][2], i);
+      }
+  }
+}
+
+// A operand of one basis tile for this lane: row = edge `er` (valid or not), k = 16 ks + 8 hh + i; slot k == B holds 1.
+template <int BT>
+__device__ __forceinline__ void painn_basis_load(const float* __restrict__ rbf, int B, int64_t er, int hh, float (&ra)[2][8]) {
+  if constexpr (BT == 20) {   // 80-B rows: 16-B pieces
+    const float4* rp = reinterpret_cast<const float4*>(rbf + er * 20);
+    const float4 t0 = rp[2 * hh], t1 = rp[2 * hh + 1], t2 = rp[4];
+    ra[0][0] = t0.x; ra[0][1] = t0.y; ra[0][2] = t0.z; ra[0][3] = t0.w;
+    ra[0][4] = t1.x; ra[0][5] = t1.y; ra[0][6] = t1.z; ra[0][7] = t1.w;
+    ra[1][0] = t2.x; ra[1][1] = t2.y; ra[1][2] = t2.z; ra[1][3] = t2.w;
+    ra[1][4] = 1.0f; ra[1][5] = 0.0f; ra[1][6] = 0.0f; ra[1][7] = 0.0f;
+  } else {
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        const int k = 16 * ks + 8 * hh + i;
+        const float x = rbf[er * B + (k < B ? k : B - 1)];
+        ra[ks][i] = k < B ? x : (k == B ? 1.0f : 0.0f);
+      }
+  }
+}
+template <int BT>
+__device__ __forceinline__ void painn_basis_split(const float (&ra)[2][8], bool valid, int hh, bf16x8 (&qa)[2][3]) {
+#pragma unroll
+  for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      bool on = valid;
+      if (BT == 20 && ks == 1) on = valid && hh == 0;   // k = 24..31 of the upper lane half: zero
+      split3_into(on ? ra[ks][i] : 0.0f, qa[ks][0], qa[ks][1], qa[ks][2], i);
+    }
+}
+
+template <int BT, bool PERM, bool ENV>
+__global__ __launch_bounds__(256, 2) void painn_message_mfma_kernel(PainnMsgArgs a) {
+  constexpr int EB = 4;     // sender rows in flight per lane: 4 x 10 loads, well inside the 6-bit vmcnt (63)
+  const int lane = threadIdx.x & 63;
+  const int fq = __builtin_amdgcn_readfirstlane(static_cast<int>(threadIdx.x >> 6));
+  const int hh = lane >> 5, c = lane & 31;
+  const int B = BT > 0 ? BT : a.B;
+  const int f0 = 32 * fq + c;
+  const int rm = (c & 3) + 4 * (c >> 3), hm = (c >> 2) & 1;   // A row c = edge rm of lane half hm
+  const int M = static_cast<int>(a.M), N = static_cast<int>(a.N);
+  const int npairs = (N + 1) >> 1;
+  int pr = static_cast<int>(mp_xcd_block(blockIdx.x, gridDim.x));
+  // first pair's edge range requested before the weights, so both fly together
+  int n = 2 * pr + hh;
+  int nc = n < N ? n : N - 1;
+  int e_lo = a.ptr[nc], e_hi = a.ptr[nc + 1];
+  bf16x8 wb[3][2][3];
+  painn_filter_operands<BT>(a.Ww, a.bw, B, f0, hh, wb);
+  for (; pr < npairs; pr += static_cast<int>(gridDim.x)) {
+    const bool has = n < N;
+    e_lo = e_lo < 0 ? 0 : (e_lo > M ? M : e_lo);
+    e_hi = e_hi < e_lo ? e_lo : (e_hi > M ? M : e_hi);
+    const int cnt = has ? e_hi - e_lo : 0;
+    const int lo0 = __builtin_amdgcn_readlane(e_lo, 0), lo1 = __builtin_amdgcn_readlane(e_lo, 32);
+    const int cnt0 = __builtin_amdgcn_readlane(cnt, 0), cnt1 = __builtin_amdgcn_readlane(cnt, 32);
+    const int maxc = cnt0 > cnt1 ? cnt0 : cnt1;
+    const int n_this = n;
+    // next pair's edge range: in flight under this pair's work
+    n = 2 * (pr + static_cast<int>(gridDim.x)) + hh;
+    nc = n < N ? n : N - 1;
+    const int nx_lo = a.ptr[nc], nx_hi = a.ptr[nc + 1];
+    float ds = 0.0f, dv[3] = {0.0f, 0.0f, 0.0f};
+    for (int cb = 0; cb < maxc; cb += 16) {
+      // ---- phase A: sender ids of this lane half's 16 edges (register order; past the end: the receiver's last edge,
+      //      whose filter row is 0) and the basis tile's row c - all requested together
+      int jr[16], er[16];
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        int slot = e_lo + (cb + r < cnt ? cb + r : (cnt > 0 ? cnt - 1 : 0));
+        slot = slot < M ? slot : M - 1;
+        er[r] = PERM ? a.perm[slot] : slot;
+      }
+#pragma unroll
+      for (int r = 0; r < 16; ++r) jr[r] = a.send[er[r]];
+      const int lo_m = hm ? lo1 : lo0, cnt_m = hm ? cnt1 : cnt0;
+      const bool rv = cb + rm < cnt_m;
+      int slot_m = lo_m + (rv ? cb + rm : 0);
+      slot_m = slot_m < M ? slot_m : M - 1;
+      const int64_t er_m = PERM ? a.perm[slot_m] : slot_m;
+      float ra[2][8];
+      painn_basis_load<BT>(a.rbf, B, er_m, hh, ra);
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int r = 0; r < 16; ++r) jr[r] = jr[r] < 0 ? 0 : (jr[r] >= N ? N - 1 : jr[r]);
+      // ---- phase B: the first batch of sender rows goes out before the matrix work, so that it flies under it
+      float sj[EB][3], vj[EB][3], rr[EB][3], ev[EB];
+      auto request = [&](int bt) {
+#pragma unroll
+        for (int u = 0; u < EB; ++u) {
+
+          const float* srow = a.s + static_cast<int64_t>(jr[bt + u]) * 3 * F + f0;
+          const float* vrow = a.v + static_cast<int64_t>(jr[bt + u]) * 3 * F + f0;
+#pragma unroll
+          for (int p = 0; p < 3; ++p) {
+            sj[u][p] = srow[p * F];
+            vj[u][p] = vrow[p * F];
+            rr[u][p] = a.rij[static_cast<int64_t>(er[bt + u]) * 3 + p];
+          }
+          ev[u] = ENV ? a.env[er[bt + u]] : 1.0f;
+        }
+      };
+      request(0);
+      __builtin_amdgcn_sched_barrier(0);
+      // ---- phase C: filter tile on the matrix pipe
+      bf16x8 qa[2][3];
+      painn_basis_split<BT>(ra, rv, hh, qa);
+      floatx16 acc[3];
+#pragma unroll
+      for (int p = 0; p < 3; ++p) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[p][r] = 0.0f;
+        acc[p] = mfma_bf16x3(qa[0], wb[p][0], acc[p]);
+        acc[p] = mfma_bf16x3(qa[1], wb[p][1], acc[p]);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      // ---- phase D: messages in edge order
+#pragma unroll
+      for (int bt = 0; bt < 16; bt += EB) {
+        if (bt > 0) {
+          if (bt >= maxc - cb) break;   // wave-uniform: neither half has edges in this batch
+          request(bt);
+        }
+#pragma unroll
+        for (int u = 0; u < EB; ++u) {
+          float sw[3];
+#pragma unroll
+          for (int p = 0; p < 3; ++p) {
+            float wv_ = acc[p][bt + u];                   // Dense: x W + b (bias = k slot B)
+            if (ENV) wv_ *= ev[u];                         // lay_mult_cutoff([w, envelope])
+            sw[p] = sj[u][p] * wv_;                        // lay_mult([s, w])
+          }
+          ds += sw[0];
+#pragma unroll
+          for (int k = 0; k < 3; ++k) dv[k] += sw[1] * vj[u][k] + sw[2] * rr[u][k];   // (sw2 * v_j) + (sw3 * r_ij)
+        }
+      }
+    }
+    if (has) {
+      if (a.z_in) {   // residual adds of PAiNN.py:126-127 fused: z + ds, v + dv
+        ds += a.z_in[static_cast<int64_t>(n_this) * F + f0];
+#pragma unroll
+        for (int k = 0; k < 3; ++k) dv[k] += a.v[(static_cast<int64_t>(n_this) * 3 + k) * F + f0];
+      }
+      a.ds[static_cast<int64_t>(n_this) * F + f0] = ds;
+#pragma unroll
+      for (int k = 0; k < 3; ++k) a.dv[(static_cast<int64_t>(n_this) * 3 + k) * F + f0] = dv[k];
+    }
+    e_lo = nx_lo;
+    e_hi = nx_hi;
+  }
+}
+
+template <int BT>
+void launch_message_mfma(const PainnMsgArgs& a, unsigned blocks, hipStream_t st) {
+  if (a.perm != nullptr) {
+    if (a.env != nullptr) painn_message_mfma_kernel<BT, true, true><<<blocks, 256, 0, st>>>(a);
+    else painn_message_mfma_kernel<BT, true, false><<<blocks, 256, 0, st>>>(a);
+  } else {
+    if (a.env != nullptr) painn_message_mfma_kernel<BT, false, true><<<blocks, 256, 0, st>>>(a);
+    else painn_message_mfma_kernel<BT, false, false><<<blocks, 256, 0, st>>>(a);
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------- message, tiles
+// The production form of the matrix-pipe message step: node TILES staged in LDS.  Measured on the kernel above (config 3):
+// what bounds the message step is not arithmetic but the vector-memory pipe - every edge pulls its sender's s_j and v_j
+// rows (3 KB) through the CU's L1, 62 MB per launch, and every wave re-reads the filter weights - with the phases of all
+// waves in step (all load, then all compute).  Batched molecular graphs have no edge between graphs, so the senders of a
+// range of receivers lie inside the receivers' own graph: a workgroup takes a tile = a few consecutive receivers of ONE
+// graph and stages
+//   * the s and v rows of the whole graph (1.5 KB + 1.5 KB per node, contiguous in memory) by LDS-DMA
+//     (global_load_lds_dwordx4: 1 KB per wave instruction, no registers, each byte crosses L1 once per tile), and
+//   * the tile's edge data - basis rows, unit vectors, sender ids, envelope: contiguous too, the edge list being
+//     receiver-sorted - through registers;
+// after ONE barrier the tile runs from LDS: filter on the matrix pipe exactly as above (A rows from the LDS basis rows,
+// B operands = the wave's slice of a pre-split bf16 image of Ww | bw, mp_painn_filter_pack_f32, 18 x 16 B per lane), the
+// sender rows by ds_read_b32 (lane = feature: conflict-free).  The tile table (receivers, graph node range, edge range per
+// tile) is built once per bound batch by the host (gcnn_keras_amd/fused_painn.py).  Unsorted edge lists (perm) and graphs
+// whose rows do not fit LDS keep the gather kernels above.
+struct PainnTileArgs {
+  const float* s;        // (N, 3F)
+  const float* v;        // (N, 3, F)
+  const float* rbf;      // (M, B)
+  const float* env;      // (M) or null
+  const float* rij;      // (M, 3)
+  const void* wimg;      // mp_painn_filter_pack_f32 image
+  const int32_t* ptr;    // (N+1) CSR over receivers (edges in receiver order: no perm)
+  const int32_t* send;   // (M)
+  const int32_t* tiles;  // (T, 8): r_lo, r_hi, s_lo, s_hi, e_lo, e_hi, -, -
+  const float* z_in;     // (N, F) or null
+  float* ds;             // (N, F)
+  float* dv;             // (N, 3, F)
+  int64_t N, M;
+  int B, ntiles, max_rows, max_edges;
+};
+
+constexpr int PAINN_FILTER_IMAGE_BYTES = 4 * 3 * 2 * 3 * 64 * 16;   // [quarter][part][k block][piece][lane] x 16 B
+
+__global__ __launch_bounds__(256) void painn_filter_pack_kernel(const float* __restrict__ Ww, const float* __restrict__ bw,
+                                                                int B, bf16x8* __restrict__ image) {
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;     // one 16-B entry per thread
+  if (t >= 4 * 3 * 2 * 3 * 64) return;
+  const int lane = t & 63, pc = (t >> 6) % 3, ks = (t / 192) & 1, p = (t / 384) % 3, fq = t / 1152;
+  const int hh = lane >> 5, col = p * F + 32 * fq + (lane & 31);
+  bf16x8 piece[3];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const int k = 16 * ks + 8 * hh + i;
+    const float x = k < B ? Ww[static_cast<int64_t>(k) * 3 * F + col] : ((k == B && bw != nullptr) ? bw[col] : 0.0f);
+    split3_into(x, piece[0], piece[1], piece[2], i);
+  }
+  image[t] = piece[pc];
+}
+
+// LDS regions of a tile, each padded to whole DMA instructions (1 KB for 16-B pieces, 256 B for dword pieces)
+__host__ __device__ __forceinline__ int painn_pad(int floats, int unit) { return ((floats + unit - 1) / unit) * unit; }
+__host__ __device__ __forceinline__ int painn_tile_lds_floats(int max_rows, int max_edges, int B, bool env) {
+  return 2 * painn_pad(max_rows * 3 * F, 256) + painn_pad(max_edges * B, 256) + painn_pad(max_edges * 3, 64) +
+         painn_pad(max_edges, 64) * (env ? 2 : 1);
+}
+
+template <int BT, bool ENV>
+__global__ __launch_bounds__(256, 2) void painn_message_tile_kernel(PainnTileArgs a) {
+  extern __shared__ __align__(16) float lds[];
+  const int lane = threadIdx.x & 63;
+  const int fq = __builtin_amdgcn_readfirstlane(static_cast<int>(threadIdx.x >> 6));
+  const int hh = lane >> 5, c = lane & 31;
+  const int B = BT > 0 ? BT : a.B;
+  const int f0 = 32 * fq + c;
+  const int rm = (c & 3) + 4 * (c >> 3), hm = (c >> 2) & 1;   // A row c = edge rm of lane half hm
+  const int node_part = painn_pad(a.max_rows * 3 * F, 256);
+  float* const Ss = lds;                                      // [rows][3F]
+  float* const Vs = Ss + node_part;                           // [rows][3][F]
+  float* const Rb = Vs + node_part;                           // [edges][B]
+  float* const Rj = Rb + painn_pad(a.max_edges * B, 256);     // [edges][3]
+  int* const Sd = reinterpret_cast<int*>(Rj + painn_pad(a.max_edges * 3, 64));   // [edges] sender ids (global)
+  float* const Ev = reinterpret_cast<float*>(Sd + painn_pad(a.max_edges, 64));   // [edges] envelope
+  // B operands: this wave's slice of the pre-split image
+  bf16x8 wb[3][2][3];
+  {
+    const bf16x8* img = reinterpret_cast<const bf16x8*>(a.wimg) + static_cast<size_t>(fq) * (3 * 2 * 3 * 64) + lane;
+#pragma unroll
+    for (int p = 0; p < 3; ++p)
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+        for (int pc = 0; pc < 3; ++pc) wb[p][ks][pc] = img[((p * 2 + ks) * 3 + pc) * 64];
+  }
+  for (int tile = static_cast<int>(mp_xcd_block(blockIdx.x, gridDim.x)); tile < a.ntiles; tile += static_cast<int>(gridDim.x)) {
+    const int4 d0 = *reinterpret_cast<const int4*>(a.tiles + static_cast<int64_t>(tile) * 8);
+    const int2 d1 = *reinterpret_cast<const int2*>(a.tiles + static_cast<int64_t>(tile) * 8 + 4);
+    const int N = static_cast<int>(a.N), M = static_cast<int>(a.M);
+    int r_lo = __builtin_amdgcn_readfirstlane(d0.x), r_hi = __builtin_amdgcn_readfirstlane(d0.y);
+    int s_lo = __builtin_amdgcn_readfirstlane(d0.z), s_hi = __builtin_amdgcn_readfirstlane(d0.w);
+    int e_lo = __builtin_amdgcn_readfirstlane(d1.x), e_hi = __builtin_amdgcn_readfirstlane(d1.y);
+    // a malformed table must not fault: everything is clamped into the arrays and into the LDS regions
+    r_lo = r_lo < 0 ? 0 : (r_lo > N ? N : r_lo);
+    r_hi = r_hi < r_lo ? r_lo : (r_hi > N ? N : r_hi);
+    if (r_hi - r_lo > 62) r_hi = r_lo + 62;
+    s_lo = s_lo < 0 ? 0 : (s_lo > N - 1 ? N - 1 : s_lo);
+    s_hi = s_hi <= s_lo ? s_lo + 1 : (s_hi > N ? N : s_hi);
+    if (s_hi - s_lo > a.max_rows) s_hi = s_lo + a.max_rows;
+    e_lo = e_lo < 0 ? 0 : (e_lo > M ? M : e_lo);
+    e_hi = e_hi < e_lo ? e_lo : (e_hi > M ? M : e_hi);
+    if (e_hi - e_lo > a.max_edges) e_hi = e_lo + a.max_edges;
+    const int rows = s_hi - s_lo, ne = e_hi - e_lo;
+    if (tile != static_cast<int>(mp_xcd_block(blockIdx.x, gridDim.x))) __syncthreads();   // the previous tile's readers are done
+    // ---- node rows by LDS-DMA: two contiguous blocks of rows * 1536 B, 1-KB chunks dealt to the four waves; a chunk's
+    //      lanes past the block re-read its last 16 B (the LDS regions are padded to whole chunks)
+    {
+      const int nfl = rows * 3 * F;                           // floats per block
+      const int chunks = (nfl + 255) / 256;
+      const float* srcS = a.s + static_cast<int64_t>(s_lo) * 3 * F;
+      const float* srcV = a.v + static_cast<int64_t>(s_lo) * 3 * F;
+      for (int ch = fq; ch < chunks; ch += 4) {
+        int off = ch * 256 + lane * 4;
+        off = off < nfl - 4 ? off : nfl - 4;
+        __builtin_amdgcn_global_load_lds(srcS + off, (__attribute__((address_space(3))) void*)(Ss + ch * 256), 16, 0, 0);
+        __builtin_amdgcn_global_load_lds(srcV + off, (__attribute__((address_space(3))) void*)(Vs + ch * 256), 16, 0, 0);
+      }
+    }
+    // ---- edge data, contiguous blocks too (the edge list is receiver-sorted): basis rows in 16-B pieces where the rows
+    //      allow it, unit vectors / sender ids / envelope as dword DMA (256 B per wave instruction).  Nothing here waits: a
+    //      rolled load -> ds_write loop costs one memory round trip per iteration.
+    {
+      const int nfl = ne * B;
+      if ((B & 3) == 0) {
+        const float* src = a.rbf + static_cast<int64_t>(e_lo) * B;
+        for (int ch = fq; ch * 256 < nfl; ch += 4) {
+          int off = ch * 256 + lane * 4;
+          off = off < nfl - 4 ? off : nfl - 4;
+          __builtin_amdgcn_global_load_lds(src + off, (__attribute__((address_space(3))) void*)(Rb + ch * 256), 16, 0, 0);
+        }
+      } else {
+        const float* src = a.rbf + static_cast<int64_t>(e_lo) * B;
+        for (int ch = fq; ch * 64 < nfl; ch += 4) {
+          int off = ch * 64 + lane;
+          off = off < nfl ? off : nfl - 1;
+          __builtin_amdgcn_global_load_lds(src + off, (__attribute__((address_space(3))) void*)(Rb + ch * 64), 4, 0, 0);
+        }
+      }
+      const float* srcr = a.rij + static_cast<int64_t>(e_lo) * 3;
+      for (int ch = fq; ch * 64 < ne * 3; ch += 4) {
+        int off = ch * 64 + lane;
+        off = off < ne * 3 ? off : ne * 3 - 1;
+        __builtin_amdgcn_global_load_lds(srcr + off, (__attribute__((address_space(3))) void*)(Rj + ch * 64), 4, 0, 0);
+      }
+      for (int ch = fq; ch * 64 < ne; ch += 4) {
+        int off = ch * 64 + lane;
+        off = off < ne ? off : ne - 1;
+        __builtin_amdgcn_global_load_lds(a.send + e_lo + off, (__attribute__((address_space(3))) void*)(Sd + ch * 64), 4, 0, 0);
+        if (ENV)
+          __builtin_amdgcn_global_load_lds(a.env + e_lo + off, (__attribute__((address_space(3))) void*)(Ev + ch * 64), 4, 0, 0);
+      }
+    }
+    // edge ranges of the tile's receivers: lane i holds ptr[r_lo + i]
+    int ptrv = a.ptr[(r_lo + lane) <= r_hi ? r_lo + lane : r_hi];
+    ptrv = ptrv < e_lo ? e_lo : (ptrv > e_hi ? e_hi : ptrv);
+    __builtin_amdgcn_s_waitcnt(0);      // DMA + stores issued by this wave have landed
+    __syncthreads();
+    // sender ids -> float offsets of the senders' staged rows (clamped into the staged range), once per tile
+    for (int i = threadIdx.x; i < ne; i += 256) {
+      int j = Sd[i] - s_lo;
+      j = j < 0 ? 0 : (j >= rows ? rows - 1 : j);
+      Sd[i] = j * 3 * F;
+    }
+    __syncthreads();
+    const int npairs = (r_hi - r_lo + 1) >> 1;
+    for (int pr = 0; pr < npairs; ++pr) {
+      const int lo0 = __builtin_amdgcn_readlane(ptrv, 2 * pr), lo1 = __builtin_amdgcn_readlane(ptrv, 2 * pr + 1);
+      const bool two = r_lo + 2 * pr + 1 < r_hi;               // wave-uniform
+      const int hi1 = two ? __builtin_amdgcn_readlane(ptrv, 2 * pr + 2) : lo1;
+      const int cnt0 = lo1 - lo0, cnt1 = hi1 - lo1;
+      const int maxc = cnt0 > cnt1 ? cnt0 : cnt1;
+      const int n = r_lo + 2 * pr + hh;
+      const bool has = hh == 0 || two;
+      const int own_lo = (hh ? lo1 : lo0) - e_lo, cnt = hh ? cnt1 : cnt0;    // local edge offsets
+      const int lo_m = (hm ? lo1 : lo0) - e_lo, cnt_m = hm ? cnt1 : cnt0;
+      float ds = 0.0f, dv[3] = {0.0f, 0.0f, 0.0f};
+      for (int cb = 0; cb < maxc; cb += 16) {
+        // A operand: row c of the tile = edge rm of receiver hm
+        const bool rv = cb + rm < cnt_m;
+        const int le_m = rv ? lo_m + cb + rm : 0;
+        float ra[2][8];
+        if constexpr (BT == 20) {
+          const float4* rp = reinterpret_cast<const float4*>(Rb + le_m * 20);
+          const float4 t0 = rp[2 * hh], t1 = rp[2 * hh + 1], t2 = rp[4];
+          ra[0][0] = t0.x; ra[0][1] = t0.y; ra[0][2] = t0.z; ra[0][3] = t0.w;
+          ra[0][4] = t1.x; ra[0][5] = t1.y; ra[0][6] = t1.z; ra[0][7] = t1.w;
+          ra[1][0] = t2.x; ra[1][1] = t2.y; ra[1][2] = t2.z; ra[1][3] = t2.w;
+          ra[1][4] = 1.0f; ra[1][5] = 0.0f; ra[1][6] = 0.0f; ra[1][7] = 0.0f;
+        } else {
+#pragma unroll
+          for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+              const int k = 16 * ks + 8 * hh + i;
+              const float x = Rb[le_m * B + (k < B ? k : B - 1)];
+              ra[ks][i] = k < B ? x : (k == B ? 1.0f : 0.0f);
+            }
+        }
+        bf16x8 qa[2][3];
+        painn_basis_split<BT>(ra, rv, hh, qa);
+        floatx16 acc[3];
+#pragma unroll
+        for (int p = 0; p < 3; ++p) {
+#pragma unroll
+          for (int r = 0; r < 16; ++r) acc[p][r] = 0.0f;
+          acc[p] = mfma_bf16x3(qa[0], wb[p][0], acc[p]);
+          acc[p] = mfma_bf16x3(qa[1], wb[p][1], acc[p]);
+        }
+        // messages in edge order.  LDS reads are issued in groups of two edges (sender offsets of the whole step first, then
+        // <= 14 read instructions per group) and each group is complete before its arithmetic: read-next-to-use exposed one
+        // LDS round trip per value (70 waits per tile in the first build), while MORE than 15 LDS reads in flight behind
+        // partial lgkmcnt waits returned stale registers in the last lanes (a 4-bit counter: seen on the hardware as wrong
+        // v' components in lanes 48-63, run to run).  Rows past the receiver's edge count have a zero filter; their reads
+        // repeat edge 0 of the tile.
+#pragma unroll
+        for (int bt = 0; bt < 16; bt += 8) {
+          if (bt < maxc - cb) {     // wave-uniform
+            int le[8], jb[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+              le[u] = cb + bt + u < cnt ? own_lo + cb + bt + u : 0;
+              jb[u] = Sd[le[u]] + f0;                            // float offset of the sender's staged rows (made above)
+            }
+#pragma unroll
+            for (int g2 = 0; g2 < 8; g2 += 2) {
+              float sj[2][3], vj[2][3], rr[2][3], ev[2];
+#pragma unroll
+              for (int u = 0; u < 2; ++u) {
+#pragma unroll
+                for (int p = 0; p < 3; ++p) {
+                  sj[u][p] = Ss[jb[g2 + u] + p * F];
+                  vj[u][p] = Vs[jb[g2 + u] + p * F];
+                  rr[u][p] = Rj[le[g2 + u] * 3 + p];
+                }
+                ev[u] = ENV ? Ev[le[g2 + u]] : 1.0f;
+              }
+              __builtin_amdgcn_sched_barrier(0);
+              __builtin_amdgcn_s_waitcnt(0xC07F);                 // lgkmcnt(0): the group's reads are here
+              __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+              for (int u = 0; u < 2; ++u) {
+                float sw[3];
+#pragma unroll
+                for (int p = 0; p < 3; ++p) {
+                  float wv_ = acc[p][bt + g2 + u];                // Dense: x W + b (bias = k slot B)
+                  if (ENV) wv_ *= ev[u];                          // lay_mult_cutoff([w, envelope])
+                  sw[p] = sj[u][p] * wv_;                         // lay_mult([s, w])
+                }
+                ds += sw[0];
+#pragma unroll
+                for (int k = 0; k < 3; ++k) dv[k] += sw[1] * vj[u][k] + sw[2] * rr[u][k];   // (sw2 * v_j) + (sw3 * r_ij)
+              }
+            }
+          }
+        }
+      }
+      if (has) {
+        if (a.z_in) {   // residual adds of PAiNN.py:126-127 fused: z + ds, v + dv (the node's own v row is staged)
+          ds += a.z_in[static_cast<int64_t>(n) * F + f0];
+          const int own = n - s_lo;
+          const int ob = (own < 0 ? 0 : (own >= rows ? rows - 1 : own)) * 3 * F + f0;
+#pragma unroll
+          for (int k = 0; k < 3; ++k)
+            dv[k] += Vs[ob + k * F];
+        }
+        a.ds[static_cast<int64_t>(n) * F + f0] = ds;
+#pragma unroll
+        for (int k = 0; k < 3; ++k) a.dv[(static_cast<int64_t>(n) * 3 + k) * F + f0] = dv[k];
+      }
+    }
   }
 }
 
@@ -651,6 +1163,18 @@ __global__ __launch_bounds__(256) void painn_geometry_bwd_kernel(const float* __
   }
 }
 
+// MPENGINE_PAINN_MFMA_GATHER=1 routes mp_painn_message_f32 to painn_message_mfma_kernel (filter on the matrix pipe, sender
+// rows gathered from global memory): measured 19.9 us against 16.2 us for the VALU build at config 3 - what the MFMAs save
+// in vector issue this form loses to its serial phases at two waves per SIMD - so it is an experiment, not the default.  The
+// default matrix-pipe route is the LDS tile kernel behind mp_painn_message_tiles_f32.
+bool painn_mfma_gather() {
+  static const bool v = [] {
+    const char* e = getenv("MPENGINE_PAINN_MFMA_GATHER");
+    return e != nullptr && e[0] == '1';
+  }();
+  return v;
+}
+
 }  // namespace
 
 extern "C" {
@@ -706,12 +1230,76 @@ int mp_painn_message_f32(const float* s, const float* v, int64_t N, const float*
   MP_REQUIRE(M < (int64_t{1} << 31) && N < (int64_t{1} << 31), "mp_painn_message_f32: sizes must fit int32");
   MP_REQUIRE(dv != v, "mp_painn_message_f32: dv must not alias v (other waves still gather v)");
   PainnMsgArgs a{s, v, rbf, env, rij, Ww, bw, ptr, perm, send, z_in, ds, dv, N, M, B};
+  hipStream_t st = mp::as_stream(stream);
+  if (B <= 31 && M > 0 && painn_mfma_gather()) {   // opt-in (see painn_mfma_gather): filter on the matrix pipe, global gathers
+    int64_t blocks = (N + 1) / 2;                    // a workgroup per receiver pair, persistent beyond two per CU
+    if (blocks > 512) blocks = 512;
+    if (B == 20) launch_message_mfma<20>(a, static_cast<unsigned>(blocks), st);
+    else launch_message_mfma<0>(a, static_cast<unsigned>(blocks), st);
+    return mp::check_launch("mp_painn_message_f32");
+  }
   int64_t blocks = mp::ceil_div(2 * N, 4);   // two waves (feature halves) per node, four waves per workgroup
   if (blocks > 4096) blocks = 4096;
-  hipStream_t st = mp::as_stream(stream);
   if (B == 20) painn_message_kernel<20><<<static_cast<unsigned>(blocks), 256, 0, st>>>(a);
   else painn_message_kernel<0><<<static_cast<unsigned>(blocks), 256, 0, st>>>(a);
   return mp::check_launch("mp_painn_message_f32");
+}
+
+int mp_painn_filter_pack_f32(const float* Ww, const float* bw, int B, void* image, mpStream_t stream) {
+  MP_REQUIRE(B >= 1 && B <= 31, "mp_painn_filter_pack_f32: the basis size must be 1..31 (K = B + 1 bias slot <= 32)");
+  MP_REQUIRE(Ww && image, "mp_painn_filter_pack_f32: null pointer");
+  painn_filter_pack_kernel<<<(PAINN_FILTER_IMAGE_BYTES / 16 + 255) / 256, 256, 0, mp::as_stream(stream)>>>(
+      Ww, bw, B, static_cast<bf16x8*>(image));
+  return mp::check_launch("mp_painn_filter_pack_f32");
+}
+
+int mp_painn_message_tiles_lds_bytes(int max_rows, int max_edges, int B, int with_env, size_t* out) {
+  MP_REQUIRE(max_rows >= 1 && max_edges >= 0 && B >= 1 && B <= 31 && out, "mp_painn_message_tiles_lds_bytes: bad arguments");
+  MP_REQUIRE(max_rows <= 4096 && max_edges <= (1 << 20), "mp_painn_message_tiles_lds_bytes: tile far beyond LDS");
+  *out = static_cast<size_t>(painn_tile_lds_floats(max_rows, max_edges, B, with_env != 0)) * 4;
+  return MP_OK;
+}
+
+int mp_painn_message_tiles_f32(const float* s, const float* v, int64_t N, const float* rbf, int B, const float* env,
+                               const float* rij, const void* wimage, const int32_t* ptr, const int32_t* send, int64_t M,
+                               const int32_t* tiles, int ntiles, int max_rows, int max_edges, const float* z_in, float* ds,
+                               float* dv, mpStream_t stream) {
+  MP_REQUIRE(N >= 0 && M >= 0 && B >= 1 && B <= 31 && ntiles >= 0, "mp_painn_message_tiles_f32: bad sizes (B must be 1..31)");
+  if (N == 0 || ntiles == 0) return MP_OK;
+  MP_REQUIRE(s && v && wimage && ptr && tiles && ds && dv && (M == 0 || (rbf && rij && send)),
+             "mp_painn_message_tiles_f32: null pointer");
+  MP_REQUIRE(M < (int64_t{1} << 31) && N < (int64_t{1} << 31), "mp_painn_message_tiles_f32: sizes must fit int32");
+  MP_REQUIRE(dv != v, "mp_painn_message_tiles_f32: dv must not alias v");
+  size_t lds = 0;
+  const int rc = mp_painn_message_tiles_lds_bytes(max_rows, max_edges, B, env != nullptr, &lds);
+  if (rc != MP_OK) return rc;
+  MP_REQUIRE(lds <= 160 * 1024, "mp_painn_message_tiles_f32: a tile of %d node rows and %d edges needs %zu B of LDS (> 160 KB)",
+             max_rows, max_edges, lds);
+  PainnTileArgs a{s, v, rbf, env, rij, wimage, ptr, send, tiles, z_in, ds, dv, N, M, B, ntiles, max_rows, max_edges};
+  hipStream_t st = mp::as_stream(stream);
+  const unsigned blocks = static_cast<unsigned>(ntiles < 2048 ? ntiles : 2048);
+  // hipFuncSetAttribute(MaxDynamicSharedMemorySize) is per device and per kernel: opted in once per (instantiation, device)
+  auto launch = [&](auto kernel) -> int {
+    static std::mutex mu;
+    static unsigned long long done = 0;       // one static pair per instantiation of this lambda's call operator
+    int dev = 0;
+    MP_HIP(hipGetDevice(&dev));
+    {
+      std::lock_guard<std::mutex> lock(mu);
+      if (dev >= 64 || !((done >> dev) & 1ull)) {
+        MP_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                   160 * 1024));
+        if (dev < 64) done |= 1ull << dev;
+      }
+    }
+    kernel<<<blocks, 256, lds, st>>>(a);
+    return MP_OK;
+  };
+  int lr;
+  if (B == 20) lr = env ? launch(painn_message_tile_kernel<20, true>) : launch(painn_message_tile_kernel<20, false>);
+  else lr = env ? launch(painn_message_tile_kernel<0, true>) : launch(painn_message_tile_kernel<0, false>);
+  if (lr != MP_OK) return lr;
+  return mp::check_launch("mp_painn_message_tiles_f32");
 }
 
 int mp_painn_message_bwd_f32(const float* s, const float* v, int64_t N, const float* rbf, const float* rbfd, int B,

@@ -15,6 +15,7 @@ saved tensor is a buffer of the batch slot.
               (sender-parallel; per-edge dE/dd, dE/dr_ij), Wphi^T, W1^T (x act') | geometry^T -> forces
 """
 import ctypes
+import os
 
 import numpy as np
 import torch
@@ -87,6 +88,14 @@ def make_images(p, depth, n_out, out=None):
         for name in (c + "dense1", c + "phi", u + "dense1", u + "a"):
             pack(name + "/P", p[name + "/kernel"])
             pack(name + "/TP", p[name + "/kernel"].t())
+        # bf16-piece operand image of the filter Dense (w = Dense(3F)(rbf), painn_conv.py:100) for the matrix-pipe message
+        # kernels; needs a free k slot for the bias (basis size <= 31)
+        wk = p[c + "w/kernel"]
+        if int(wk.shape[0]) <= 31:
+            if out is None:
+                images[c + "w/F"] = torch.empty(_ffi.MP_PAINN_FILTER_IMAGE_BYTES, dtype=torch.uint8, device=wk.device)
+            _ffi.call("mp_painn_filter_pack_f32", _ffi.ptr(wk), _ffi.ptr(p.get(c + "w/bias")), int(wk.shape[0]),
+                      _ffi.ptr(images[c + "w/F"]), _ffi.stream())
     for k in range(n_out):
         put("output_mlp/%d/T" % k, p["output_mlp/%d/kernel" % k].t())
     torch.cuda.current_stream().synchronize()   # the packed sources in `keep` are temporaries
@@ -132,6 +141,7 @@ class FusedPainn:
             raise IndexError("edge index out of range for its graph")
         self.ptr0, self.perm0, _ = plan.csr(0)
         self.ptr1, self.perm1, _ = plan.csr(1) if self.grad else (None, None, None)
+        self.tiles0 = self._tile_table(node, self.ptr0, self.perm0, self.B + 4 + (1 if self.cos_cutoff > 0 else 0))
         mm = max(m, 1)
         self.recv = torch.empty(mm, dtype=torch.int32, device=dev)
         self.send = torch.empty(mm, dtype=torch.int32, device=dev)
@@ -170,6 +180,41 @@ class FusedPainn:
         self.graphs = {}
         self.rings = {}
 
+    def _tile_table(self, node, ptr, perm, floats_per_edge):
+        """Tiles of the LDS-staged message kernels (csrc/mp_painn_fused.hip): a few consecutive nodes of ONE graph, the
+        graph's node range (whose s / v rows the workgroup stages) and the tile's edge range in the CSR ``ptr`` - built
+        once per bound batch on the host (the CSR is read back: a few KB, next to the flag word bind reads anyway).
+        None when the kernels do not apply: permuted (unsorted) edge lists, basis sizes without a free bias slot, graphs
+        whose node rows do not fit LDS."""
+        n = int(node.values.shape[0])
+        if perm is not None or self.B > 31 or n == 0 or self.M == 0 or os.environ.get("MPENGINE_PAINN_TILES") == "0":
+            return None
+        ns = np.asarray(node.row_splits_host(), dtype=np.int64)
+        sizes = ns[1:] - ns[:-1]
+        per = int(os.environ.get("MPENGINE_PAINN_TILE_R", "0")) or max(2, 2 * int(-(-n // 1024)))   # nodes per tile: >= 512 tiles
+        per = min(per, 62)
+        count = -(-sizes // per)                                      # tiles per graph
+        total = int(count.sum())
+        if total == 0:
+            return None
+        graph = np.repeat(np.arange(len(sizes)), count)
+        first = np.cumsum(count) - count
+        k = np.arange(total) - np.repeat(first, count)
+        r_lo = ns[graph] + k * per
+        r_hi = np.minimum(r_lo + per, ns[graph + 1])
+        ptr_host = ptr.cpu().numpy().astype(np.int64)
+        table = np.zeros((total, 8), dtype=np.int32)
+        table[:, 0], table[:, 1], table[:, 2], table[:, 3] = r_lo, r_hi, ns[graph], ns[graph + 1]
+        table[:, 4], table[:, 5] = ptr_host[r_lo], ptr_host[r_hi]
+        max_rows, max_edges = int(sizes.max()), int((table[:, 5] - table[:, 4]).max())
+        lds = ctypes.c_size_t(0)
+        _ffi.call("mp_painn_message_tiles_lds_bytes", max_rows, max_edges, self.B, 1, ctypes.byref(lds))
+        # the reverse kernel stages g_ds (F) + g_dv (3F) per node and two basis tables per edge: never more than this
+        if lds.value + max_edges * 4 * (self.B + 1) > 160 * 1024:
+            return None
+        return {"table": torch.from_numpy(table).to(node.values.device), "count": total, "max_rows": max_rows,
+                "max_edges": max_edges}
+
     # ------------------------------------------------------------------------------------------------ launches
     @staticmethod
     def _dense(x, rows, k, w, b, u, out, act=0, out_pre=None, grad_act=0, grad_pre=None, addend=None):
@@ -204,10 +249,17 @@ class FusedPainn:
             # Dense(act) writes the activation and (for the reverse pass) keeps the pre-activation h1 beside it
             self._chain(z, n, 128, w[c + "dense1/P"], p.get(c + "dense1/bias"), 128, t["s"], act=self.act_conv,
                         save_pre=t["h1"] if self.grad else None, w2=w[c + "phi/P"], b2=p.get(c + "phi/bias"), u2=384)
-            _ffi.call("mp_painn_message_f32", _ffi.ptr(t["s"]), _ffi.ptr(v), n, _ffi.ptr(self.rbf), self.B,
-                      _ffi.ptr(self.env), _ffi.ptr(self.rij), _ffi.ptr(p[c + "w/kernel"]), _ffi.ptr(p.get(c + "w/bias")),
-                      _ffi.ptr(self.ptr0), _ffi.ptr(self.perm0), _ffi.ptr(self.send), m, _ffi.ptr(z), _ffi.ptr(t["zp"]),
-                      _ffi.ptr(t["vp"]), _ffi.stream())
+            tl = self.tiles0
+            if tl is not None and (c + "w/F") in w:   # node tiles in LDS, filter on the matrix pipe
+                _ffi.call("mp_painn_message_tiles_f32", _ffi.ptr(t["s"]), _ffi.ptr(v), n, _ffi.ptr(self.rbf), self.B,
+                          _ffi.ptr(self.env), _ffi.ptr(self.rij), _ffi.ptr(w[c + "w/F"]), _ffi.ptr(self.ptr0),
+                          _ffi.ptr(self.send), m, _ffi.ptr(tl["table"]), tl["count"], tl["max_rows"], tl["max_edges"],
+                          _ffi.ptr(z), _ffi.ptr(t["zp"]), _ffi.ptr(t["vp"]), _ffi.stream())
+            else:
+                _ffi.call("mp_painn_message_f32", _ffi.ptr(t["s"]), _ffi.ptr(v), n, _ffi.ptr(self.rbf), self.B,
+                          _ffi.ptr(self.env), _ffi.ptr(self.rij), _ffi.ptr(p[c + "w/kernel"]),
+                          _ffi.ptr(p.get(c + "w/bias")), _ffi.ptr(self.ptr0), _ffi.ptr(self.perm0), _ffi.ptr(self.send), m,
+                          _ffi.ptr(z), _ffi.ptr(t["zp"]), _ffi.ptr(t["vp"]), _ffi.stream())
             self._chain(t["vp"], 3 * n, 128, w["uv%d/P" % i], None, 256, t["uv"])
             # PAiNNUpdate's element-wise steps (norm / scalar product before, the gated residual updates after) are the
             # prologue and the epilogue of its two-layer chain: one launch; c, prod, a reach HBM for the reverse pass only

@@ -315,6 +315,20 @@ int mp_painn_stage0_f32(const void* numbers /* float32, or int64 if numbers_i64 
 int mp_painn_message_f32(const float* s, const float* v, int64_t N, const float* rbf, int B, const float* env,
                          const float* rij, const float* Ww, const float* bw, const int32_t* ptr, const int32_t* perm,
                          const int32_t* send, int64_t M, const float* z_in, float* ds, float* dv, mpStream_t stream);
+/* The same message step with node TILES staged in LDS and the filter Dense (painn_conv.py:100, w = Dense(3F)(rbf)) on the
+ * matrix pipe (FP32-exact bf16-piece split, csrc/mp_painn_fused.hip): for receiver-sorted edge lists (no perm) of batched
+ * graphs.  tiles (T,8) int32 = {r_lo, r_hi, s_lo, s_hi, e_lo, e_hi, 0, 0}: receivers [r_lo, r_hi) (at most 62) of ONE graph
+ * whose nodes are [s_lo, s_hi) (<= max_rows: the s / v rows staged) and whose edges are [e_lo, e_hi) = [ptr[r_lo],
+ * ptr[r_hi]) (<= max_edges); every receiver must appear in exactly one tile.  wimage: mp_painn_filter_pack_f32 of Ww | bw
+ * (MP_PAINN_FILTER_IMAGE_BYTES, rebuilt when the weights change).  LDS per workgroup: mp_painn_message_tiles_lds_bytes
+ * (<= 160 KB, else MP_EINVAL).  Results as mp_painn_message_f32 (same accumulation order per receiver). */
+#define MP_PAINN_FILTER_IMAGE_BYTES 73728
+int mp_painn_filter_pack_f32(const float* Ww, const float* bw, int B, void* image, mpStream_t stream);
+int mp_painn_message_tiles_lds_bytes(int max_rows, int max_edges, int B, int with_env, size_t* out);
+int mp_painn_message_tiles_f32(const float* s, const float* v, int64_t N, const float* rbf, int B, const float* env,
+                               const float* rij, const void* wimage, const int32_t* ptr, const int32_t* send, int64_t M,
+                               const int32_t* tiles, int ntiles, int max_rows, int max_edges, const float* z_in, float* ds,
+                               float* dv, mpStream_t stream);
 /* Reverse pass of the message block (painn_conv.py:99-113) for forces: sender-parallel over the CSR of column 1
  * (ptr1 / perm1).  Given g_ds (N,F) and g_dv (N,3,F): g_s (N,3F) = dE/ds, g_v (N,3,F) = g_dv + dE/dv through the
  * messages (nullable), and per edge dE/dd (through the filter: rbfd = d rbf / d d, envelope by the product rule) and

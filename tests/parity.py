@@ -73,8 +73,10 @@ def assert_forces_close(force, ref32, ref64, node_splits, what="", rtol=FORCE_RT
       sum of cancelling pair terms, so in float32 the small rows of a molecule carry errors of ~1e-7 of the molecule's
       scale whoever computes them (at ``floor`` = 1e-3 the float32 reference itself has rows 1e-4 off on config 3), and
       WHICH molecule draws the bad row is rounding luck.  The statement that holds for a correct float32 pipeline is
-      rank-wise: sorted over molecules, the engine's k-th largest row error is within ``max(rtol, 2 x`` the float32
-      reference's k-th largest``)`` for every k.
+      rank-wise: sorted over molecules, the engine's k-th largest row error is within ``max(rtol, 4 x`` the float32
+      reference's k-th largest``)`` for every k (``assert_rows_close`` allows the engine 4x the oracle's distance from
+      float64 for the worst row only; here the same factor binds at every rank), and the engine's median is within
+      ``max(rtol, 2 x`` the reference's median``)``.
     Prints both distributions; returns (worst max-norm error, worst row error)."""
     f, r32, r64 = (np.asarray(a, np.float64).reshape(-1, 3) for a in (force, ref32, ref64))
     assert f.shape == r64.shape == r32.shape, (f.shape, r32.shape, r64.shape)
@@ -103,7 +105,9 @@ def assert_forces_close(force, ref32, ref64, node_splits, what="", rtol=FORCE_RT
           "worst %.2e median %.2e, %d above %.0e | float32 reference worst %.2e median %.2e, %d above %.0e" % (
               what, len(norm_e), max(norm_e), float(np.median(norm_e)), floor, eng[0], float(np.median(eng)),
               int(np.sum(eng > rtol)), rtol, ref[0], float(np.median(ref)), int(np.sum(ref > rtol)), rtol))
-    bad = np.nonzero(eng > np.maximum(rtol, 2 * ref))[0]
+    bad = np.nonzero(eng > np.maximum(rtol, 4 * ref))[0]
     assert bad.size == 0, "%s: rank %d atom-row error %.3g vs float32 reference %.3g at the same rank" % (
         what, int(bad[0]), eng[bad[0]], ref[bad[0]])
+    assert np.median(eng) <= max(rtol, 2 * float(np.median(ref))), "%s: median atom-row error %.3g vs reference %.3g" % (
+        what, float(np.median(eng)), float(np.median(ref)))
     return max(norm_e), float(eng[0])
