@@ -624,7 +624,7 @@ __global__ __launch_bounds__(256) void painn_filter_pack_kernel(const float* __r
 __host__ __device__ __forceinline__ int painn_pad(int floats, int unit) { return ((floats + unit - 1) / unit) * unit; }
 __host__ __device__ __forceinline__ int painn_tile_lds_floats(int max_rows, int max_edges, int B, bool env) {
   return 2 * painn_pad(max_rows * 3 * F, 256) + painn_pad(max_edges * B, 256) + painn_pad(max_edges * 3, 64) +
-         painn_pad(max_edges, 64) * (env ? 2 : 1);
+         painn_pad(max_edges, 64) * (env ? 2 : 1) + painn_pad(max_edges * 4, 64);
 }
 
 template <int BT, bool ENV>
@@ -643,6 +643,7 @@ __global__ __launch_bounds__(256, 2) void painn_message_tile_kernel(PainnTileArg
   float* const Rj = Rb + painn_pad(a.max_edges * B, 256);     // [edges][3]
   int* const Sd = reinterpret_cast<int*>(Rj + painn_pad(a.max_edges * 3, 64));   // [edges] sender ids (global)
   float* const Ev = reinterpret_cast<float*>(Sd + painn_pad(a.max_edges, 64));   // [edges] envelope
+  float4* const P4 = reinterpret_cast<float4*>(Ev + (ENV ? painn_pad(a.max_edges, 64) : 0));   // [edges] {r_ij, envelope}
   // B operands: this wave's slice of the pre-split image
   bf16x8 wb[3][2][3];
   {
@@ -727,10 +728,12 @@ __global__ __launch_bounds__(256, 2) void painn_message_tile_kernel(PainnTileArg
     __builtin_amdgcn_s_waitcnt(0);      // DMA + stores issued by this wave have landed
     __syncthreads();
     // sender ids -> float offsets of the senders' staged rows (clamped into the staged range), once per tile
+    // and the edge's unit vector + envelope as ONE 16-B entry (one LDS read per edge instead of four)
     for (int i = threadIdx.x; i < ne; i += 256) {
       int j = Sd[i] - s_lo;
       j = j < 0 ? 0 : (j >= rows ? rows - 1 : j);
       Sd[i] = j * 3 * F;
+      P4[i] = make_float4(Rj[3 * i], Rj[3 * i + 1], Rj[3 * i + 2], ENV ? Ev[i] : 1.0f);
     }
     __syncthreads();
     const int npairs = (r_hi - r_lo + 1) >> 1;
@@ -777,12 +780,12 @@ __global__ __launch_bounds__(256, 2) void painn_message_tile_kernel(PainnTileArg
           acc[p] = mfma_bf16x3(qa[0], wb[p][0], acc[p]);
           acc[p] = mfma_bf16x3(qa[1], wb[p][1], acc[p]);
         }
-        // messages in edge order.  LDS reads are issued in groups of two edges (sender offsets of the whole step first, then
-        // <= 14 read instructions per group) and each group is complete before its arithmetic: read-next-to-use exposed one
-        // LDS round trip per value (70 waits per tile in the first build), while MORE than 15 LDS reads in flight behind
-        // partial lgkmcnt waits returned stale registers in the last lanes (a 4-bit counter: seen on the hardware as wrong
-        // v' components in lanes 48-63, run to run).  Rows past the receiver's edge count have a zero filter; their reads
-        // repeat edge 0 of the tile.
+        // messages in edge order.  LDS reads are issued in groups of two edges - the step's eight sender offsets first, then
+        // per group 2 x (3 + 3 + 1) = 14 read instructions at most - and each group is complete (lgkmcnt(0)) before its
+        // arithmetic.  The LGKM counter has four bits: with MORE than 15 LDS reads in flight behind partial waits, registers
+        // were consumed before their data had arrived (wrong v' components in lanes 48-63, varying from run to run, seen
+        // on the hardware with 72 reads in flight); read-next-to-use on the other hand exposes one LDS round trip per
+        // value.  Rows past the receiver's edge count have a zero filter; their reads repeat edge 0 of the tile.
 #pragma unroll
         for (int bt = 0; bt < 16; bt += 8) {
           if (bt < maxc - cb) {     // wave-uniform
@@ -792,34 +795,38 @@ __global__ __launch_bounds__(256, 2) void painn_message_tile_kernel(PainnTileArg
               le[u] = cb + bt + u < cnt ? own_lo + cb + bt + u : 0;
               jb[u] = Sd[le[u]] + f0;                            // float offset of the sender's staged rows (made above)
             }
+            __builtin_amdgcn_sched_barrier(0);
+            __builtin_amdgcn_s_waitcnt(0xC07F);                   // lgkmcnt(0)
+            __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int g2 = 0; g2 < 8; g2 += 2) {
-              float sj[2][3], vj[2][3], rr[2][3], ev[2];
+              float sj[2][3], vj[2][3];
+              float4 re[2];
 #pragma unroll
               for (int u = 0; u < 2; ++u) {
 #pragma unroll
                 for (int p = 0; p < 3; ++p) {
                   sj[u][p] = Ss[jb[g2 + u] + p * F];
                   vj[u][p] = Vs[jb[g2 + u] + p * F];
-                  rr[u][p] = Rj[le[g2 + u] * 3 + p];
                 }
-                ev[u] = ENV ? Ev[le[g2 + u]] : 1.0f;
+                re[u] = P4[le[g2 + u]];
               }
               __builtin_amdgcn_sched_barrier(0);
               __builtin_amdgcn_s_waitcnt(0xC07F);                 // lgkmcnt(0): the group's reads are here
               __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
               for (int u = 0; u < 2; ++u) {
+                const float rr[3] = {re[u].x, re[u].y, re[u].z};
                 float sw[3];
 #pragma unroll
                 for (int p = 0; p < 3; ++p) {
                   float wv_ = acc[p][bt + g2 + u];                // Dense: x W + b (bias = k slot B)
-                  if (ENV) wv_ *= ev[u];                          // lay_mult_cutoff([w, envelope])
+                  if (ENV) wv_ *= re[u].w;                        // lay_mult_cutoff([w, envelope])
                   sw[p] = sj[u][p] * wv_;                         // lay_mult([s, w])
                 }
                 ds += sw[0];
 #pragma unroll
-                for (int k = 0; k < 3; ++k) dv[k] += sw[1] * vj[u][k] + sw[2] * rr[u][k];   // (sw2 * v_j) + (sw3 * r_ij)
+                for (int k = 0; k < 3; ++k) dv[k] += sw[1] * vj[u][k] + sw[2] * rr[k];   // (sw2 * v_j) + (sw3 * r_ij)
               }
             }
           }

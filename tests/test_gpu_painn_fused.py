@@ -174,7 +174,7 @@ def test_message_tiles_in_lds_against_gather_route_and_limits(monkeypatch):
     got = gather_model(x2)
     assert gather_model.fused.slot_of(x2).tiles0 is None
     assert_rows_close(got.cpu().numpy(), ref32, ref64, what="PaiNN forward, gather kernels")
-    assert rowwise_rel(got.cpu().numpy(), first.cpu().numpy()) <= 2e-6
+    assert rowwise_rel(got.cpu().numpy(), first.cpu().numpy()) <= 2e-5     # two float32 pipelines, each within 1e-5 of the oracle
     monkeypatch.delenv("MPENGINE_PAINN_TILES")
     blk = slot.blk[0]
     with pytest.raises(ValueError):
