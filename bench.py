@@ -156,6 +156,33 @@ def pmc_traffic(kernel_name, graphs):
     return {"traffic": None}
 
 
+def pmc_matrix_pipe(kernel_name, graphs, avg_launch_us):
+    """Matrix-pipe occupancy of the dominant kernel from the committed SQ counter pass (profiles/r*_pmc_mfma.json,
+    scripts/run_pmc_mfma.sh): SQ_VALU_MFMA_BUSY_CYCLES per launch (32 per v_mfma_f32_32x32x16_bf16) over the cycles of
+    all 1024 SIMDs - once with the kernel's cycles from GRBM_GUI_ACTIVE / 8 (the chip's own clock under load; reads high on
+    dispatches shorter than ~0.3 ms, so the share reads LOW there) and once with this run's measured launch time at the
+    2.4 GHz the roofline peak is quoted at.  Empty when no pass exists for this workload size."""
+    import glob
+    want = {128: "config 2", 12500: "12500 graphs"}.get(graphs)
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "*pmc_mfma.json")), reverse=True):
+        try:
+            for entry in json.load(open(path)):
+                if want and entry["label"].startswith(want):
+                    for k, v in entry["kernels"].items():
+                        if k.split("<")[0] in kernel_name and v.get("SQ_VALU_MFMA_BUSY_CYCLES"):
+                            busy = v["SQ_VALU_MFMA_BUSY_CYCLES"]
+                            out = {"source": os.path.basename(path), "SQ_VALU_MFMA_BUSY_CYCLES": busy,
+                                   "SQ_INSTS_VALU": v.get("SQ_INSTS_VALU"),
+                                   "kernel_cycles_grbm": v.get("kernel_cycles"),
+                                   "matrix_pipe_busy_grbm_clock": v.get("matrix_pipe_busy")}
+                            if avg_launch_us:
+                                out["matrix_pipe_busy_at_2p4GHz"] = busy / (1024.0 * avg_launch_us * 1e-6 * 2.4e9)
+                            return {"matrix_pipe_pmc": out}
+        except Exception:
+            continue
+    return {}
+
+
 class _Dist:
     """torch.distributed plumbing of one rank (RCCL = backend "nccl"; gloo only rehearses N > 1 on a one-GPU box)."""
 
@@ -260,6 +287,7 @@ def run_config2(args, d):
     torch.cuda.set_stream(torch.cuda.default_stream())
     roof = fwd.roofline(HBM_PEAK_GBS, FP32_MFMA_PEAK_TF)  # dominant kernel, timed with HIP events on its stream
     roof.update(pmc_traffic(roof.get("kernel", ""), n_graphs))
+    roof.update(pmc_matrix_pipe(roof.get("kernel", ""), n_graphs, roof.get("avg_launch_us")))
     roof["measured"] = ("HIP events on the kernel's stream around back-to-back launches of the kernel alone on the GPU "
                         "(50 launches per HIP-graph replay, so that the host's call rate is not what is timed), after "
                         "the timed region; rocprofv3 --kernel-trace --stats of `bench.py --in-flight 1` (profiles/) "
@@ -364,6 +392,7 @@ def run_config4(args, d, standalone=True):
     slot = model.fused.slot_of(inputs)
     roof = slot.roofline(HBM_PEAK_GBS, FP32_MFMA_PEAK_TF, iters=10)
     roof["measured"] = "HIP events on the kernel's stream around back-to-back launches of the kernel alone, after the timed region"
+    roof.update(pmc_matrix_pipe(roof.get("kernel", ""), n_graphs, roof.get("avg_launch_us")))
     model.fused.release()
     if d.rank != 0:
         return None
