@@ -242,9 +242,33 @@ def ptr(t):
     return c_void_p(t.data_ptr())
 
 
+_raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", None)
+_raw_device = getattr(torch._C, "_cuda_getDevice", None)
+
+
+def stream_handle():
+    """Integer hipStream_t of torch's current stream.  ``torch.cuda.current_stream().cuda_stream`` builds a Stream object
+    and resolves the device index through several Python layers (~5 us, three times per model call before); the two C
+    entry points underneath it take ~0.3 us."""
+    if _raw_stream is not None and _raw_device is not None:
+        return _raw_stream(_raw_device())
+    return torch.cuda.current_stream().cuda_stream
+
+
 def stream():
     """hipStream_t of torch's current stream (torch is plumbing: memory + streams)."""
-    return c_void_p(torch.cuda.current_stream().cuda_stream)
+    return c_void_p(stream_handle())
+
+
+_has_gpu = None
+
+
+def has_gpu():
+    """``torch.cuda.is_available()`` once per process (the call reads environment variables every time)."""
+    global _has_gpu
+    if _has_gpu is None:
+        _has_gpu = bool(torch.cuda.is_available())
+    return _has_gpu
 
 
 _launches = [0]

@@ -107,6 +107,62 @@ def pack_weights(p, depth, bins, out=None):
     return out
 
 
+def _round_up(x, unit):
+    return ((max(int(x), 1) + unit - 1) // unit) * unit
+
+
+class WorkSet:
+    """Work buffers of one batch slot at a bucketed capacity, reusable by later batches of similar size, plus the
+    direct-launch descriptor whose weight and work-buffer fields are filled once.  ``agg`` is zero between forwards (the
+    node kernels re-zero the rows they consume, rows beyond a batch's N are never written), ``flags`` is zero unless a
+    kernel flagged an error, so a recycled set needs no fill launch."""
+    __slots__ = ("n_cap", "m_cap", "g_cap", "recv", "send", "dist", "flags", "n", "x", "agg", "h", "desc", "stream_key")
+
+    def __init__(self, n_cap, m_cap, g_cap, stream_key):
+        dev = "cuda"
+        self.n_cap, self.m_cap, self.g_cap, self.stream_key = n_cap, m_cap, g_cap, stream_key
+        self.recv = torch.empty(m_cap, dtype=torch.int32, device=dev)
+        self.send = torch.empty(m_cap, dtype=torch.int32, device=dev)
+        self.dist = torch.empty(m_cap, dtype=torch.float32, device=dev)
+        self.flags = torch.zeros(1, dtype=torch.int32, device=dev)
+        self.n = torch.empty((n_cap, 128), dtype=torch.float32, device=dev)
+        self.x = torch.empty((n_cap, 128), dtype=torch.float32, device=dev)
+        self.agg = torch.zeros((n_cap, 128), dtype=torch.float32, device=dev)
+        self.h = torch.empty((n_cap, 64), dtype=torch.float32, device=dev)
+        self.desc = None
+
+
+class WorkArena:
+    """Free work sets of a route, per (stream, size bucket).  A batch that is seen once (``model.predict`` over a dataset,
+    kgcnn/data/base.py:203-239) binds, launches and is dropped; its ~10 work tensors then cost ~30 us of allocator calls
+    and three fill launches per batch - more host time than the forward's eight launches.  Sets are handed back when their
+    slot object dies and re-issued only to binds under the SAME stream (stream order is what makes the reuse safe: the
+    previous owner's kernels were queued on that stream before the next owner's)."""
+    N_UNIT, M_UNIT, G_UNIT = 512, 8192, 64
+
+    def __init__(self, max_free=32):
+        self.free = {}
+        self.max_free = max_free
+        self.taken = self.made = 0
+
+    def take(self, stream_key, n, m, g):
+        key = (stream_key, _round_up(n, self.N_UNIT), _round_up(m, self.M_UNIT), _round_up(g, self.G_UNIT))
+        bucket = self.free.get(key)
+        if bucket:
+            self.taken += 1
+            return bucket.pop()
+        self.made += 1
+        return WorkSet(key[1], key[2], key[3], stream_key)
+
+    def give(self, ws):
+        bucket = self.free.setdefault((ws.stream_key, ws.n_cap, ws.m_cap, ws.g_cap), [])
+        if len(bucket) < self.max_free:
+            bucket.append(ws)
+
+    def clear(self):
+        self.free.clear()
+
+
 class FusedSchnet:
     """One batch slot of the fused forward: work buffers, a HIP stream and the captured graph of ONE bound batch.
 
@@ -116,7 +172,7 @@ class FusedSchnet:
 
     def __init__(self, params, depth=3, gauss_args=None, fast_softplus=True, use_graph=True, cfconv_flags=0,
                  packed=None):
-        if not torch.cuda.is_available():
+        if not _ffi.has_gpu():
             raise _ffi.EngineError("FusedSchnet needs an MI355X (no CPU fallback)")
         self.depth = depth
         self.gauss = dict(gauss_args or {"bins": 20, "distance": 4, "offset": 0.0, "sigma": 0.4})
@@ -124,8 +180,11 @@ class FusedSchnet:
         self._stream_ptr = None
         self._desc = self._desc_ref = None
         self.use_graph = use_graph
-        self.p = {k: (v if torch.is_tensor(v) else torch.from_numpy(np.ascontiguousarray(v, dtype=np.float32)).cuda())
-                  for k, v in params.items() if v is not None}
+        if packed is not None:      # a route's slot: ``params`` is the route's dictionary of live device tensors
+            self.p = params
+        else:
+            self.p = {k: (v if torch.is_tensor(v) else torch.from_numpy(np.ascontiguousarray(v, dtype=np.float32)).cuda())
+                      for k, v in params.items() if v is not None}
         self.emb_dim = int(self.p["embedding"].shape[1])
         if self.emb_dim not in (64, 128) or tuple(self.p["dense0/kernel"].shape) != (self.emb_dim, 128):
             raise ValueError("FusedSchnet is built for embedding width 64 / 128 and 128 units")
@@ -140,31 +199,51 @@ class FusedSchnet:
         if "node_bf" in images and os.environ.get("MPENGINE_NODE_BF16", "1") != "0":
             self.node_images = images["node_bf"]
             self.flags_arg |= 64
-        self.stream = torch.cuda.Stream()
-        self.graph = None
+        self._own_stream = None     # made on first use (capture / engine.SchnetForward): a slot that is bound, launched
+        self.graph = None           # once and dropped never needs one
         self._ring = None
         self.num_launches = 1 + 2 * depth + 1
         self._b = None
+        self._work = self._arena = None
+        self._foreign_stream = False
+
+    @property
+    def stream(self):
+        if self._own_stream is None:
+            self._own_stream = torch.cuda.Stream()
+        return self._own_stream
+
+    @stream.setter
+    def stream(self, value):
+        self._own_stream = value
 
     # ------------------------------------------------------------------------------------------------ binding
-    def bind(self, b, n, m, g, known_flags=None):
-        """Attach a resident batch (dict of device tensors: z, xyz, idx, ns, es + host node splits) and allocate all
-        work buffers on the current stream.  ``known_flags``: the MP_FLAG_* word of the index list if a producer (host
-        packer, on-GPU SetRange) already established it - otherwise one index pass runs and its flag word is read back
-        (the only host synchronisation of a batch's life, on the current stream only)."""
+    def bind(self, b, n, m, g, known_flags=None, arena=None):
+        """Attach a resident batch (dict of device tensors: z, xyz, idx, ns, es + host node splits) and take its work
+        buffers - from ``arena`` (a route's ``WorkArena``: a recycled set of the size bucket, nothing allocated, nothing
+        filled) or freshly allocated on the current stream.  ``known_flags``: the MP_FLAG_* word of the index list if a
+        producer (host packer, on-GPU SetRange) already established it - otherwise one index pass runs and its flag word is
+        read back (the only host synchronisation of a batch's life, on the current stream only)."""
         self._b, self.N, self.M, self.G = b, n, m, g
         i64 = 256 if b["z"].dtype == torch.int64 else 0      # flags bit 8: int64 node numbers (the fork's input dtype)
         self.node_flags = (self.flags_arg & (3 | 64)) | i64
         dev = "cuda"
-        self.recv = torch.empty(max(m, 1), dtype=torch.int32, device=dev)
-        self.send = torch.empty(max(m, 1), dtype=torch.int32, device=dev)
-        self.dist = torch.empty(max(m, 1), dtype=torch.float32, device=dev)
-        self.flags = torch.zeros(1, dtype=torch.int32, device=dev)
-        self.n = torch.empty((n, 128), dtype=torch.float32, device=dev)
-        self.x = torch.empty((n, 128), dtype=torch.float32, device=dev)
-        self.agg = torch.zeros((n, 128), dtype=torch.float32, device=dev)
-        self.h = torch.empty((n, 64), dtype=torch.float32, device=dev)
-        self.out = torch.zeros((g, 1), dtype=torch.float32, device=dev)
+        if arena is not None:
+            ws = arena.take(_ffi.stream_handle(), n, m, g)
+            self._work, self._arena = ws, arena
+            self.recv, self.send, self.dist, self.flags = ws.recv, ws.send, ws.dist, ws.flags
+            self.n, self.x, self.agg, self.h = ws.n, ws.x, ws.agg, ws.h
+            self.out = torch.empty((g, 1), dtype=torch.float32, device=dev)   # the readout writes every row
+        else:
+            self.recv = torch.empty(max(m, 1), dtype=torch.int32, device=dev)
+            self.send = torch.empty(max(m, 1), dtype=torch.int32, device=dev)
+            self.dist = torch.empty(max(m, 1), dtype=torch.float32, device=dev)
+            self.flags = torch.zeros(1, dtype=torch.int32, device=dev)
+            self.n = torch.empty((n, 128), dtype=torch.float32, device=dev)
+            self.x = torch.empty((n, 128), dtype=torch.float32, device=dev)
+            self.agg = torch.zeros((n, 128), dtype=torch.float32, device=dev)
+            self.h = torch.empty((n, 64), dtype=torch.float32, device=dev)
+            self.out = torch.zeros((g, 1), dtype=torch.float32, device=dev)
         self.perm = self.recv_sorted = self.sort_ws = None
         # sortedness of the receiver column is a property of the batch: decide once, outside the timed region
         if known_flags is None:
@@ -280,7 +359,9 @@ class FusedSchnet:
         if got is None:
             return None
         (out,), graph = got
-        _ffi.call("mp_graph_launch", graph, _ffi.stream())
+        st = _ffi.stream()
+        self._note_stream(st)
+        _ffi.call("mp_graph_launch", graph, st)
         return out if self.out_rows == self.G else out[:self.out_rows]
 
     def _capture_synced(self, out):
@@ -298,11 +379,36 @@ class FusedSchnet:
         self.graph = None
         self._ring = None
 
+    def _note_stream(self, st):
+        """A recycled work set goes back to the arena of the stream it was taken under; a slot that was also launched on
+        another stream is not recycled (its last kernels are not ordered before that stream's next bind)."""
+        if self._work is not None and (st.value or 0) != self._work.stream_key:   # c_void_p(0).value is None
+            self._foreign_stream = True
+
+    def hand_out_static(self):
+        """The static result buffer itself as the caller's tensor (first, direct call of an arena-bound batch: no copy
+        launch).  The slot makes a new static buffer if it ever needs one again."""
+        self._out_handed = True
+        return self.out if self.out_rows == self.G else self.out[:self.out_rows]
+
+    def _fresh_static(self):
+        if getattr(self, "_out_handed", False):
+            self._out_handed = False
+            self.out = torch.zeros((self.G, 1), dtype=torch.float32, device="cuda")
+            if self._desc is not None:
+                self._desc.out = self.out.data_ptr()
+            if self.graph is not None:        # captured against the buffer the caller now owns
+                _ffi.call("mp_graph_destroy", self.graph)
+                self.graph = None
+
     def run_current(self, how="graph"):
         """One forward of the bound batch on torch's CURRENT stream (ordinary stream semantics for the caller):
         ``graph`` replays the captured forward (captured on first use), ``direct`` issues the eight launches from one
         C-ABI call (``mp_schnet_forward_launch``), ``eager`` issues them one engine call each.  Returns this slot's
         static ``(G', 1)`` output buffer."""
+        self._fresh_static()
+        st = _ffi.stream()
+        self._note_stream(st)
         if how == "graph":
             if self.graph is None:
                 torch.cuda.current_stream().synchronize()
@@ -358,12 +464,23 @@ class FusedSchnet:
     def _descriptor(self):
         """``mp_schnet_forward_desc`` of the bound batch (receiver-sorted batches only)."""
         p, b, ga, w = self.p, self._b, self.gauss, self.node_images
+        addr = lambda t: None if t is None else t.data_ptr()
+        ws = self._work
+        if ws is not None and ws.desc is not None:   # a recycled set: only the batch's own fields change
+            d = ws.desc
+            d.N, d.M, d.G = self.N, self.M, self.G
+            d.flags = self.flags_arg | (self.node_flags & 256)
+            d.numbers, d.xyz, d.idx = addr(b["z"]), addr(b["xyz"]), addr(b["idx"])
+            d.node_splits, d.edge_splits = addr(b["ns"]), addr(b["es"])
+            d.out = addr(self.out)
+            return d
         d = _ffi.SchnetForwardDesc()
+        if ws is not None:
+            ws.desc = d
         d.N, d.M, d.G = self.N, self.M, self.G
         d.depth, d.vocab, d.bins = self.depth, int(p["embedding"].shape[0]), int(ga["bins"])
         d.flags = self.flags_arg | (self.node_flags & 256)
         d.g_distance, d.g_sigma, d.g_offset = float(ga["distance"]), float(ga["sigma"]), float(ga["offset"])
-        addr = lambda t: None if t is None else t.data_ptr()
         d.numbers, d.xyz, d.idx = addr(b["z"]), addr(b["xyz"]), addr(b["idx"])
         d.node_splits, d.edge_splits = addr(b["ns"]), addr(b["es"])
         d.embedding, d.W0, d.b0 = addr(p["embedding"]), addr(w["dense0/kernel"]), addr(p.get("dense0/bias"))
@@ -402,6 +519,8 @@ class FusedSchnet:
     def check_flags(self):
         torch.cuda.synchronize()
         f = int(self.flags.item())
+        if f and self._work is not None:
+            self.flags.zero_()          # the word belongs to a recycled work set: the next owner starts clean
         if f & _ffi.MP_FLAG_OOB:
             raise IndexError("edge index out of range for its graph")
         if self.sorted and (f & _ffi.MP_FLAG_UNSORTED_COL0):
@@ -459,6 +578,9 @@ class FusedSchnet:
     def __del__(self):
         try:
             self._drop_graphs()
+            if self._work is not None and self._arena is not None and not self._foreign_stream:
+                self._arena.give(self._work)     # every launch of this slot ran on the stream the set belongs to
+            self._work = None
         except Exception:
             pass
 
@@ -488,6 +610,7 @@ class SchnetFusedRoute:
         self._wkey = None
         self._wlist, self._vsum, self._wcalls, self._wepoch = None, 0, 0, -1
         self._packed = None
+        self._arena = WorkArena()   # recycled work-buffer sets (batches that are bound, launched once and dropped)
         self._grad_images = None    # transposed kernels / cfconv reverse images, built on the first force call
         self.single_state = True    # SchNet heads the route accepts end in one energy value per graph
         self.last = None            # how the last call ran: "direct" | "graph" | "eager"
@@ -536,6 +659,7 @@ class SchnetFusedRoute:
         if moved:                  # other tensors: every bound slot (descriptor, graph) points at the old ones
             self._slots.clear()
             self._gslots.clear()
+            self._arena.clear()    # cached descriptors hold the old weight addresses
             self._grad_images = None
             self._p = {k: v for k, v in p.items() if v is not None}
             self._packed = pack_weights(self._p, self.depth, int(self.gauss["bins"]))
@@ -563,7 +687,8 @@ class SchnetFusedRoute:
         for plan in idx._plans.values():   # a producer (host packer, on-GPU SetRange) may have classified the list already
             if plan._flags_host is not None:
                 known = plan._flags_host
-        slot.bind(batch, int(node.values.shape[0]), int(idx.values.shape[0]), node.nrows(), known_flags=known)
+        slot.bind(batch, int(node.values.shape[0]), int(idx.values.shape[0]), node.nrows(), known_flags=known,
+                  arena=self._arena)
         slot.calls = 0
         return slot
 
@@ -589,7 +714,11 @@ class SchnetFusedRoute:
             if out is not None:
                 return out
         out = slot.run_current(how)
-        return out.clone() if self.copy_output else out
+        if not self.copy_output:
+            return out
+        if how == "direct" and slot.calls == 1 and slot._work is not None:
+            return slot.hand_out_static()   # first sight: the slot's result buffer becomes the caller's tensor, no copy
+        return out.clone()
 
     def energy_force(self, inputs):
         """``(energy (G', 1), force (N, 3))`` with force = -dE/dx: fused forward + hand-written reverse pass, one HIP
@@ -637,4 +766,5 @@ class SchnetFusedRoute:
         torch.cuda.synchronize()
         self._slots.clear()
         self._gslots.clear()
+        self._arena.clear()
         self._wlist = None

@@ -91,8 +91,9 @@ class Model:
     @staticmethod
     def _graph_key(inputs):
         import torch
+        from .. import _ffi
         from ..ragged import RaggedTensor
-        if not torch.cuda.is_available() or not isinstance(inputs, (list, tuple)):
+        if not _ffi.has_gpu() or not isinstance(inputs, (list, tuple)):
             return None
         key = []
         for x in inputs:
