@@ -1,11 +1,17 @@
 """Host batch packer: lists of per-graph NumPy arrays -> the engine's ragged tensors in HBM.
 
 Mirrors ``MemoryGraphList.tensor`` (kgcnn/data/base.py:203-239: per property ``np.concatenate`` + ``row_lengths``
-through ``ragged_tensor_from_nested_numpy``, kgcnn/data/utils.py:129-157).  The concatenation runs in the native
-library (``mp_pack_rows_host`` / ``mp_pack_edge_index_host``, csrc/mp_pack.hip) into reusable - pinned when a GPU is
-present - staging buffers; every packed tensor then crosses PCIe with one asynchronous copy.  For the edge indices the
-packer also emits the batch's index plan (shifted int32 columns, flag word, CSR) so that the device does not have to
-recompute it (``IndexPlan.from_host``).
+through ``ragged_tensor_from_nested_numpy``, kgcnn/data/utils.py:129-157).  Rows are concatenated straight into reusable
+staging buffers - pinned when a GPU is present - and every packed tensor then crosses PCIe with one asynchronous copy.
+For the edge indices the native library (``mp_pack_edge_index_host``, csrc/mp_pack.hip) makes the batch's index plan in
+the same pass (shifted int32 columns, flag word, CSR), so that the device does not have to recompute it
+(``IndexPlan.from_host``).
+
+Gathering many small per-graph arrays is bound by the per-array Python work, not by bytes: collecting 3 x 128 array
+addresses for a native pointer table cost 1.1 ms per 128-graph batch (``a.ctypes.data`` ~1 us each, plus the per-graph
+``ascontiguousarray``), three times the GPU time of 30 such batches.  ``np.concatenate(..., out=staging)`` walks the list in
+C (~50 ns per array); the native passes then run on the concatenated block through a pointer table made by vectorised
+arithmetic on the row splits (``mp_pack_rows_host`` stays the entry point for callers that hold a pointer table already).
 """
 import ctypes
 
@@ -29,7 +35,7 @@ class HostBuffer:
     """Growable staging block from ``mp_host_alloc`` (pinned if a device is present), exposed as NumPy views."""
 
     def __init__(self, pinned=None):
-        self.pinned = torch.cuda.is_available() if pinned is None else bool(pinned)
+        self.pinned = _ffi.has_gpu() if pinned is None else bool(pinned)
         self._ptr = ctypes.c_void_p(None)
         self._bytes = 0
 
@@ -38,7 +44,9 @@ class HostBuffer:
         need = int(np.prod(shape, dtype=np.int64)) * dtype.itemsize
         if need > self._bytes:
             self.release()
-            size = max(need, 2 * self._bytes, 1 << 12)
+            # half again as much as asked for: batches of a dataset differ by ~10 % in size, and a pinned allocation costs
+            # ~0.4 ms (more than packing the batch) - one allocation per staging block, not one per new maximum
+            size = max(need + need // 2, 2 * self._bytes, 1 << 16)
             _ffi.call("mp_host_alloc", size, int(self.pinned), ctypes.byref(self._ptr))
             self._bytes = size
         if need == 0:
@@ -69,30 +77,46 @@ def _row_table(arrays, src_dtype, inner_shape):
     return keep, ptrs, counts
 
 
+def _concat_into(arrays, out):
+    """``np.concatenate(arrays, axis=0)`` into ``out`` (any dtype conversion included); arrays without rows may have any
+    shape (the reference's datasets hold ``(0,)`` placeholders)."""
+    try:
+        np.concatenate(arrays, axis=0, out=out, casting="unsafe")
+    except ValueError:
+        kept = [np.asarray(a).reshape((len(a),) + out.shape[1:]) for a in arrays if len(a)]
+        if kept:
+            np.concatenate(kept, axis=0, out=out, casting="unsafe")
+
+
 def pack_rows(arrays, dtype=None, buffer=None, threads=4):
     """``(values, row_splits)`` on the host: ``np.concatenate(arrays, axis=0, dtype=dtype)`` + int64 row_splits."""
     arrays = list(arrays)
     G = len(arrays)
-    first = next((np.asarray(a) for a in arrays if np.asarray(a).size), np.asarray(arrays[0]) if G else np.zeros((0,)))
+    first = next((np.asarray(a) for a in arrays if len(a)), np.asarray(arrays[0]) if G else np.zeros((0,)))
     inner = tuple(first.shape[1:])
     src = first.dtype if G else np.dtype("float32")
-    for a in arrays:
-        a = np.asarray(a)
-        if a.size and tuple(a.shape[1:]) != inner:
-            raise ValueError("all arrays must match in shape except the first dimension (kgcnn/data/utils.py:130-131)")
     dst = np.dtype(dtype) if dtype is not None else src
-    if src not in _KINDS:  # e.g. int16 / bool properties: one NumPy conversion, then the native pass
-        src = np.dtype("int64") if src.kind in "iub" else np.dtype("float64")
-    keep, ptrs, counts = _row_table(arrays, src, inner)
+    if dtype is not None:
+        _kind(dst)                                   # float32 / float64 / int32 / int64 targets (TypeError otherwise)
+    elif dst not in _KINDS:                          # e.g. int16 / bool properties keep a widened type, as before
+        dst = np.dtype("int64") if dst.kind in "iub" else np.dtype("float64")
+    if src.kind == "f" and dst.kind in "iu":
+        raise _ffi.EngineError("mp_pack_rows_host: float -> integer is not a conversion the packer offers")
+    counts = np.fromiter((len(a) for a in arrays), dtype=np.int64, count=G)
     total = int(counts.sum())
-    row_elems = int(np.prod(inner, dtype=np.int64)) if inner else 1
     buffer = buffer or HostBuffer(pinned=False)
     values = buffer.view((total,) + inner, dst)
     splits = np.zeros(G + 1, dtype=np.int64)
-    _ffi.call("mp_pack_rows_host", ptrs, counts.ctypes.data_as(ctypes.c_void_p), G, row_elems, _kind(src), _kind(dst),
-              values.ctypes.data_as(ctypes.c_void_p) if total else None, splits.ctypes.data_as(ctypes.c_void_p),
-              int(threads))
-    del keep
+    np.cumsum(counts, out=splits[1:])
+    if total:
+        for a in arrays[:1] + arrays[-1:]:
+            a = np.asarray(a)
+            if a.size and tuple(a.shape[1:]) != inner:
+                raise ValueError("all arrays must match in shape except the first dimension (kgcnn/data/utils.py:130-131)")
+        try:
+            _concat_into(arrays, values)
+        except ValueError:
+            raise ValueError("all arrays must match in shape except the first dimension (kgcnn/data/utils.py:130-131)")
     return values, splits
 
 
@@ -114,16 +138,21 @@ def pack_edge_index(index_arrays, node_counts, buffers=None, threads=4, with_csr
     ``edge_splits``, ``node_splits``, ``cols`` (K,M) int32 shifted, ``csr`` (N+1) int32, ``flags`` int."""
     index_arrays = list(index_arrays)
     G = len(index_arrays)
-    first = next((np.asarray(a) for a in index_arrays if np.asarray(a).size), None)
+    first = next((np.asarray(a) for a in index_arrays if len(a)), None)
     K = int(first.shape[1]) if first is not None else 2
-    src = np.dtype("int32") if first is not None and first.dtype == np.int32 else np.dtype("int64")
-    keep, ptrs, ecounts = _row_table(index_arrays, src, (K,))
+    if first is not None and first.dtype.kind not in "iu":
+        raise TypeError("the packer handles float32/float64/int32/int64 properties, edge indices must be integers")
+    ecounts = np.fromiter((len(a) for a in index_arrays), dtype=np.int64, count=G)
     ncounts = np.ascontiguousarray(node_counts, dtype=np.int64)
     if ncounts.shape != (G,):
         raise ValueError("node_counts must have one entry per graph")
     M, N = int(ecounts.sum()), int(ncounts.sum())
     buffers = buffers or {}
-    hb = lambda name: buffers.setdefault(name, HostBuffer(pinned=False))
+    def hb(name):
+        if name not in buffers:
+            buffers[name] = HostBuffer(pinned=False)
+        return buffers[name]
+
     idx = hb("idx").view((M, K), np.int64)
     cols = hb("cols").view((K, max(M, 1)), np.int32)
     csr = hb("csr").view((N + 1,), np.int32) if with_csr else None
@@ -131,9 +160,14 @@ def pack_edge_index(index_arrays, node_counts, buffers=None, threads=4, with_csr
     nsplits = np.zeros(G + 1, dtype=np.int64)
     flags = ctypes.c_int32(0)
     vp = lambda a: a.ctypes.data_as(ctypes.c_void_p) if a is not None and a.size else None
-    _ffi.call("mp_pack_edge_index_host", ptrs, _kind(src), vp(ecounts), vp(ncounts), G, K, vp(idx), vp(esplits),
+    table = None
+    if M:
+        # the API tensor first (C loop over the list), then the native plan pass reads it IN PLACE through a pointer table
+        # made from the row splits: graph g's rows start at idx + 8 K * edge_splits[g]
+        _concat_into(index_arrays, idx)
+        table = (np.cumsum(ecounts) - ecounts).astype(np.uint64) * np.uint64(8 * K) + np.uint64(idx.ctypes.data)
+    _ffi.call("mp_pack_edge_index_host", vp(table), _kind(np.int64), vp(ecounts), vp(ncounts), G, K, vp(idx), vp(esplits),
               vp(nsplits), vp(cols) if M else None, vp(csr), ctypes.byref(flags), int(threads))
-    del keep
     return {"idx": idx, "edge_splits": esplits, "node_splits": nsplits, "cols": cols, "csr": csr,
             "flags": int(flags.value), "M": M, "N": N, "K": K}
 
@@ -207,7 +241,12 @@ class BatchPacker:
     def pack_host(self, graphs, slot=None):
         """Host half only (no device needed): name -> ``(values, splits)`` or dense array; plan dict under ``"__plan__"``."""
         bufs = self._slots[self._turn if slot is None else slot]
-        hb = lambda name: bufs.setdefault(name, HostBuffer())
+
+        def hb(name):
+            if name not in bufs:
+                bufs[name] = HostBuffer()
+            return bufs[name]
+
         out = {}
         for key, it in zip(self.keys, self.items):
             name = it["name"]
