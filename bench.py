@@ -314,6 +314,7 @@ def run_config2(args, d):
                            "stream) are in flight, so kernels of different batches share the GPU" % slots,
                    "sharding": "by graph, 1 all-gather of predictions per step" if world > 1 else "single GPU"},
         "single_forward_latency_ms": latency_ms,
+        "stream_placement": fwd.placement,   # in-flight streams: best of the draws is used; a random draw gives the median
         "roofline": roof,
         "forward_model": {"hbm_frac": fwd_bytes / (ms_per_step * 1e-3) / (HBM_PEAK_GBS * 1e9),
                           "mfma_frac": fwd_flops / (ms_per_step * 1e-3) / (FP32_MFMA_PEAK_TF * 1e12),

@@ -75,6 +75,7 @@ class SchnetForward:
         self._inputs = []
         self._streams = []
         self._slots = []
+        self.placement = None
         self.in_flight = max(1, int(in_flight)) if mode == "fused" else 1
         # several forwards in flight use the same 4-wave cfconv build as a lone forward (flag bit 4 - the 8-wave build,
         # two waves per SIMD on one LDS image - measured equal within run-to-run spread: 634 vs 621 M edges/s, and it
@@ -142,13 +143,18 @@ class SchnetForward:
             torch.cuda.synchronize()
             return time.perf_counter() - t0
 
-        best, best_streams = None, None
+        best, best_streams, seen = None, None, []
         for _ in range(draws):
             t = max(rate(), rate())
+            seen.append(t / steps)
             if best is None or t < best:
                 best, best_streams = t, list(self._streams)
             self._streams = [torch.cuda.Stream() for _ in range(self.in_flight)]
         self._streams = best_streams
+        seen.sort()
+        # what a caller who simply takes four streams from torch's pool gets is a random draw: the median beside the best
+        self.placement = {"draws": draws, "steps_per_draw": steps, "best_us_per_step": seen[0] * 1e6,
+                          "median_us_per_step": seen[len(seen) // 2] * 1e6, "worst_us_per_step": seen[-1] * 1e6}
         torch.cuda.synchronize()
 
     @staticmethod
