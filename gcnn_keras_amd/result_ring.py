@@ -4,8 +4,8 @@ A Keras model call returns a NEW tensor.  A captured HIP graph writes to fixed a
 the slot's static result into a fresh allocation after every replay - a launch of its own per result (4.3 us of a 64 us
 SchNet forward at BASELINE config 2).  Instead a slot keeps a few result sets, each with its own captured graph (the same
 kernels on the same work buffers - only the destination of the final kernels differs), and hands a set out only while
-nobody else holds one of its tensors or a view of them: storage use count and Python reference count are back at the
-values they had when only the ring held the tensor.  To the caller that is indistinguishable from a fresh tensor - a
+nobody else holds one of its tensors, a view of them or their storage: storage use count and the Python reference counts
+of the tensor and of its storage wrapper are back at the values they had when only the ring held the tensor.  To the caller that is indistinguishable from a fresh tensor - a
 result somebody still holds is never written again - and a loop that drops its results runs on the ring alone.  When
 every set is held the caller falls back to a static set and a copy.
 """
@@ -20,7 +20,11 @@ _USE_COUNT = getattr(torch._C, "_storage_Use_Count", None)   # private torch API
 
 
 def _holders(t):
-    return _USE_COUNT(t.untyped_storage()._cdata), sys.getrefcount(t)
+    """(storage use count, references to the tensor object, references to its Python storage wrapper).  The third catches
+    a caller who keeps only ``out.untyped_storage()``: torch preserves and re-uses the wrapper object, so the first two
+    counts stay at their idle values while the wrapper's own reference count is one higher."""
+    st = t.untyped_storage()
+    return _USE_COUNT(st._cdata), sys.getrefcount(t), sys.getrefcount(st)
 
 
 class ResultRing:

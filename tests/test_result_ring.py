@@ -46,3 +46,16 @@ def test_loop_that_drops_its_results_cycles_through_the_ring():
         out = ring.acquire(make, capture)[0][0]         # `out` keeps the previous result alive during the call
         seen.add(out.data_ptr())
     assert len(made) == 3 and len(seen) == 3            # the ring fills up first, then its sets are taken round robin
+
+
+def test_a_caller_holding_only_the_storage_blocks_the_set():
+    """``out.untyped_storage()`` kept by the caller (no tensor, no view): torch re-uses the storage's Python wrapper, so use
+    count and tensor reference count look idle - the wrapper's own reference count gives the holder away."""
+    ring, make, capture, made, captured = _ring(size=1)
+    (e1, f1), g1 = ring.acquire(make, capture)
+    storage = e1.untyped_storage()
+    del e1, f1
+    assert ring.acquire(make, capture) is None
+    del storage
+    got = ring.acquire(make, capture)
+    assert got is not None and got[1] is g1
