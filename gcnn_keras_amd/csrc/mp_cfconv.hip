@@ -899,10 +899,12 @@ int launch_by_basis(const CfconvArgs& args, int waves, int grid, bool compact, h
   (void)compact;   // flag bit 4 selects the 8-wave build in cfconv_dispatch (two waves per SIMD on ONE LDS image)
   // basis sizes with a compile-time k count run GEMM1 on the bf16 pipe: 20 (SchNet default) and 25 (the fork's
   // force_schnet.py configuration); everything else takes the generic FP32 GEMM1
-  if (waves == 8) {
-    if (args.B == 20) return launch_cfconv<8, GAUSS, FAST, 11, false>(args, grid, s);
-    if (args.B == 25) return launch_cfconv<8, GAUSS, FAST, 13, false>(args, grid, s);
-    return launch_cfconv<8, GAUSS, FAST, 0, false>(args, grid, s);
+  // the 8-wave build (256 registers per wave) exists for the fast-softplus, fixed-basis builds only: with the exact
+  // softplus or the generic FP32 GEMM1 it spilled (2-27 registers, 12-112 B of scratch per lane: a scratch segment is paid
+  // for at every launch) - cfconv_dispatch gives those the 4-wave build
+  if constexpr (FAST) {
+    if (waves == 8 && args.B == 20) return launch_cfconv<8, GAUSS, FAST, 11, false>(args, grid, s);
+    if (waves == 8 && args.B == 25) return launch_cfconv<8, GAUSS, FAST, 13, false>(args, grid, s);
   }
   if (args.B == 20) return launch_cfconv<4, GAUSS, FAST, 11, false>(args, grid, s);
   if (args.B == 25) return launch_cfconv<4, GAUSS, FAST, 13, false>(args, grid, s);
@@ -927,6 +929,7 @@ int cfconv_dispatch(CfconvArgs args, bool gauss, int flags, hipStream_t s) {
   int waves = args.ntiles >= 4096 ? 8 : 4;
   if (flags & 4) waves = 8;
   if (flags & 8) waves = 4;
+  if (!(fast && (args.B == 20 || args.B == 25))) waves = 4;   // no spill-free 8-wave build for these (launch_by_basis)
   // Flag bit 4 ("several forwards in flight"): every workgroup claims a whole CU (all its registers, 107-120 KB of LDS), so
   // forwards of different batches share the GPU only CU by CU; with this flag a launch uses half as many workgroups, two
   // tiles per wave - the per-workgroup fixed cost (launch ramp, 107 KB of weight staging) is paid once per eight tiles

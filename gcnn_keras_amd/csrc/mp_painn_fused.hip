@@ -1238,11 +1238,10 @@ int mp_painn_message_f32(const float* s, const float* v, int64_t N, const float*
   MP_REQUIRE(dv != v, "mp_painn_message_f32: dv must not alias v (other waves still gather v)");
   PainnMsgArgs a{s, v, rbf, env, rij, Ww, bw, ptr, perm, send, z_in, ds, dv, N, M, B};
   hipStream_t st = mp::as_stream(stream);
-  if (B <= 31 && M > 0 && painn_mfma_gather()) {   // opt-in (see painn_mfma_gather): filter on the matrix pipe, global gathers
+  if (B == 20 && M > 0 && painn_mfma_gather()) {   // opt-in experiment (see painn_mfma_gather), 20-function basis build only
     int64_t blocks = (N + 1) / 2;                    // a workgroup per receiver pair, persistent beyond two per CU
     if (blocks > 512) blocks = 512;
-    if (B == 20) launch_message_mfma<20>(a, static_cast<unsigned>(blocks), st);
-    else launch_message_mfma<0>(a, static_cast<unsigned>(blocks), st);
+    launch_message_mfma<20>(a, static_cast<unsigned>(blocks), st);   // (the generic-basis build of this form spills)
     return mp::check_launch("mp_painn_message_f32");
   }
   int64_t blocks = mp::ceil_div(2 * N, 4);   // two waves (feature halves) per node, four waves per workgroup
