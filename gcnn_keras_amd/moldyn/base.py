@@ -10,7 +10,12 @@ post-processors, a list of graphs out (kgcnn/moldyn/base.py:106-165).  MI355X sp
 * with ``use_graph=True`` the model call - forward AND the reverse pass of an ``EnergyForceModel`` - is captured once
   per topology in a HIP graph and replayed while the edge list stays the same (the reference's own
   ``update_from_last_input=["range_indices"]`` neighbour-list reuse): an MD step is then one pinned copy of the new
-  coordinates plus one graph launch instead of several hundred launches from Python.
+  coordinates plus one graph launch instead of several hundred launches from Python;
+* while the integer inputs (edge lists, partitions) of consecutive calls are equal - the MD loop between two neighbour-list
+  updates - the step does not go through the packer at all (round 3): the float properties are concatenated into
+  persistent pinned blocks and copied straight into the captured graph's input tensors, the graph is replayed, and all
+  outputs come back through pinned blocks behind ONE stream synchronisation (0.59 -> 0.32 ms per step for the 21-atom
+  PaiNN case: what remains is the 26-launch energy + force pass itself).
 """
 import time
 
@@ -53,7 +58,9 @@ class MolDynamicsModelPredictor:
         self._counter = 0
         self._packer = None
         self._graphed = None       # (topology signature, GraphedModel, device inputs)
+        self._fast = None          # same-topology path: cached integer inputs + pinned staging of the float ones
         self.graph_captures = 0
+        self.fast_steps = 0
 
     def load(self, file_path: str):
         raise NotImplementedError("Not yet supported.")
@@ -121,6 +128,7 @@ class MolDynamicsModelPredictor:
         sig = self._signature(tensor_input)
         if self._graphed is None or self._graphed[0] != sig:
             self._graphed = (sig, GraphedModel(self.model, tensor_input), tensor_input)
+            self._fast = None
             self.graph_captures += 1
         else:
             _, _, bound = self._graphed
@@ -130,6 +138,63 @@ class MolDynamicsModelPredictor:
                 if d.dtype.is_floating_point and d.data_ptr() != s.data_ptr():
                     d.copy_(s, non_blocking=True)
         return self._graphed[1]()
+
+    # ---- same-topology step (use_graph) --------------------------------------------------------------------------
+    def _fast_state(self, graph_list):
+        """Cache what identifies the bound topology on the host (every integer property of every graph) and make the
+        pinned staging for the float properties; None when the fast step does not apply (device-side preprocessors
+        derive inputs from the coordinates, dense items)."""
+        if self.tensor_preprocessors or self._graphed is None:
+            return None
+        items = self._items()
+        ints, floats = [], []
+        for pos, it in enumerate(items):
+            bound = self._graphed[2][pos]
+            if not it.get("ragged", False) or not isinstance(bound, RaggedTensor):
+                return None
+            props = [np.asarray(g[it["name"]]) for g in graph_list]
+            if bound.values.dtype.is_floating_point:
+                stage = torch.empty(tuple(bound.values.shape), dtype=bound.values.dtype, pin_memory=True)
+                floats.append((it["name"], bound.values, stage, stage.numpy(), [len(p) for p in props]))
+            else:
+                ints.append((it["name"], [p.copy() for p in props]))
+        return {"n": len(graph_list), "ints": ints, "floats": floats, "out": None}
+
+    def _fast_step(self, graph_list):
+        """One MD step on the bound topology, or None if this call does not match it."""
+        st = self._fast
+        if st is None or len(graph_list) != st["n"]:
+            return None
+        for name, cached in st["ints"]:
+            for g, ref in zip(graph_list, cached):
+                cur = g[name]
+                if cur is not ref and not np.array_equal(cur, ref):
+                    return None
+        for name, dst, stage, view, lens in st["floats"]:
+            props = [g[name] for g in graph_list]
+            if [len(p) for p in props] != lens:
+                return None
+            np.concatenate(props, axis=0, out=view, casting="unsafe")
+            dst.copy_(stage, non_blocking=True)
+        out = self._graphed[1]()
+        tensor_dict = self._translate_properties(out, self.model_outputs)
+        if st["out"] is None:       # pinned blocks for the outputs, one per returned tensor
+            st["out"] = {k: torch.empty(tuple((v.values if isinstance(v, RaggedTensor) else v).shape),
+                                        dtype=(v.values if isinstance(v, RaggedTensor) else v).dtype, pin_memory=True)
+                         for k, v in tensor_dict.items()}
+        for k, v in tensor_dict.items():
+            st["out"][k].copy_((v.values if isinstance(v, RaggedTensor) else v).detach(), non_blocking=True)
+        torch.cuda.current_stream().synchronize()
+        host = {}
+        for k, v in tensor_dict.items():
+            arr = st["out"][k].numpy()
+            if isinstance(v, RaggedTensor):
+                s_ = v.row_splits_host()
+                host[k] = [arr[s_[i]:s_[i + 1]] for i in range(len(s_) - 1)]
+            else:
+                host[k] = arr
+        self.fast_steps += 1
+        return host
 
     def __call__(self, graph_list):
         """List of graphs in -> ``MemoryGraphList`` of output graphs (kgcnn/moldyn/base.py:106-165)."""
@@ -147,12 +212,15 @@ class MolDynamicsModelPredictor:
         if self.store_last_input:
             self._last_input = graph_list.copy() if self.copy_graphs_in_store else graph_list
 
-        tensor_output = self._call_model(self._tensor_input(graph_list))
-        tensor_dict = self._translate_properties(tensor_output, self.model_outputs)
-
-        host = {}
-        for key, value in tensor_dict.items():
-            host[key] = value.numpy_rows() if isinstance(value, RaggedTensor) else value.detach().cpu().numpy()
+        host = self._fast_step(graph_list) if self.use_graph else None
+        if host is None:
+            tensor_output = self._call_model(self._tensor_input(graph_list))
+            tensor_dict = self._translate_properties(tensor_output, self.model_outputs)
+            host = {}
+            for key, value in tensor_dict.items():
+                host[key] = value.numpy_rows() if isinstance(value, RaggedTensor) else value.detach().cpu().numpy()
+            if self.use_graph and self._fast is None:
+                self._fast = self._fast_state(graph_list)
         output_list = []
         for i in range(num_samples):
             temp_dict = GraphDict({key: np.array(value[i]) for key, value in host.items()})

@@ -100,6 +100,7 @@ def test_graph_replayed_md_steps_equal_eager_and_recapture_on_new_topology():
         assert np.max(np.abs(got[0]["forces"] - ref[0]["forces"])) <= 1e-5 * scale
         xyz = xyz + rng.normal(scale=0.01, size=xyz.shape).astype(np.float32)
     assert fast.graph_captures == 1
+    assert fast.fast_steps >= 2                           # same neighbour list: the steps after the capture skip the packer
     b2 = dict(b)
     keep = np.ones(len(b["edge_indices"]), dtype=bool)
     keep[3] = False                                       # one pair leaves the cutoff: new topology -> new graph
@@ -109,6 +110,10 @@ def test_graph_replayed_md_steps_equal_eager_and_recapture_on_new_topology():
     got = fast(_graphs(b2, xyz))
     assert fast.graph_captures == 2
     _check_against_oracle(got, b2, xyz, what="MD step on the new topology")
+    steps_before = fast.fast_steps
+    again = fast(_graphs(b2, xyz + 0.01))                 # ... and the fast step follows the new capture
+    assert fast.fast_steps == steps_before + 1
+    _check_against_oracle(again, b2, xyz + 0.01, what="MD fast step on the new topology")
     assert np.max(np.abs(got[0]["forces"] - ref[0]["forces"])) <= 1e-5 * np.max(np.abs(ref[0]["forces"]))
     t_eager = eager._test_timing(_graphs(b2, xyz), repetitions=5)
     t_fast = fast._test_timing(_graphs(b2, xyz), repetitions=5)
