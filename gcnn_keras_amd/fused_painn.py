@@ -102,6 +102,41 @@ def make_images(p, depth, n_out, out=None):
     return images
 
 
+def message_tile_table(node_splits, ptr, basis, per=None, lds_limit=160 * 1024):
+    """Tile table of ``mp_painn_message_tiles_f32`` (csrc/mp_painn_fused.hip) from host arrays: ``(T, 8)`` int32 rows
+    ``{r_lo, r_hi, s_lo, s_hi, e_lo, e_hi, 0, 0}`` - a few consecutive nodes ``[r_lo, r_hi)`` of ONE graph, the graph's node
+    range ``[s_lo, s_hi)`` (whose s / v rows the workgroup stages: a tile's senders lie in its own graph) and the tile's
+    edge range ``[ptr[r_lo], ptr[r_hi])`` in the receiver CSR.  ``per`` nodes per tile (default: enough tiles for two
+    workgroups per CU, at least 2, at most 62).  Returns ``{"table", "count", "max_rows", "max_edges"}`` or None when a
+    graph's rows and a tile's edge data do not fit ``lds_limit`` bytes of LDS."""
+    ns = np.asarray(node_splits, dtype=np.int64)
+    ptr = np.asarray(ptr, dtype=np.int64)
+    n = int(ns[-1]) if len(ns) else 0
+    if n == 0 or basis > 31:
+        return None
+    sizes = ns[1:] - ns[:-1]
+    per = int(per) if per else max(2, 2 * int(-(-n // 1024)))
+    per = max(1, min(per, 62))
+    count = -(-sizes // per)                                      # tiles per graph
+    total = int(count.sum())
+    if total == 0:
+        return None
+    graph = np.repeat(np.arange(len(sizes)), count)
+    first = np.cumsum(count) - count
+    k = np.arange(total) - np.repeat(first, count)
+    r_lo = ns[graph] + k * per
+    r_hi = np.minimum(r_lo + per, ns[graph + 1])
+    table = np.zeros((total, 8), dtype=np.int32)
+    table[:, 0], table[:, 1], table[:, 2], table[:, 3] = r_lo, r_hi, ns[graph], ns[graph + 1]
+    table[:, 4], table[:, 5] = ptr[r_lo], ptr[r_hi]
+    max_rows, max_edges = int(sizes.max()), int((table[:, 5] - table[:, 4]).max())
+    lds = ctypes.c_size_t(0)
+    _ffi.call("mp_painn_message_tiles_lds_bytes", max_rows, max_edges, int(basis), 1, ctypes.byref(lds))
+    if lds.value > lds_limit:
+        return None
+    return {"table": table, "count": total, "max_rows": max_rows, "max_edges": max_edges}
+
+
 class FusedPainn:
     """One batch slot: buffers, the two captured graphs (energy only; energy + forces) of ONE bound batch."""
 
@@ -181,39 +216,19 @@ class FusedPainn:
         self.rings = {}
 
     def _tile_table(self, node, ptr, perm, floats_per_edge):
-        """Tiles of the LDS-staged message kernels (csrc/mp_painn_fused.hip): a few consecutive nodes of ONE graph, the
-        graph's node range (whose s / v rows the workgroup stages) and the tile's edge range in the CSR ``ptr`` - built
-        once per bound batch on the host (the CSR is read back: a few KB, next to the flag word bind reads anyway).
-        None when the kernels do not apply: permuted (unsorted) edge lists, basis sizes without a free bias slot, graphs
-        whose node rows do not fit LDS."""
+        """Tiles of the LDS-staged message kernel for this batch (``message_tile_table``), on the device; None when the
+        kernel does not apply: permuted (unsorted) edge lists, basis sizes without a free bias slot, graphs whose node
+        rows do not fit LDS, ``MPENGINE_PAINN_TILES=0``."""
         n = int(node.values.shape[0])
         if perm is not None or self.B > 31 or n == 0 or self.M == 0 or os.environ.get("MPENGINE_PAINN_TILES") == "0":
             return None
-        ns = np.asarray(node.row_splits_host(), dtype=np.int64)
-        sizes = ns[1:] - ns[:-1]
-        per = int(os.environ.get("MPENGINE_PAINN_TILE_R", "0")) or max(2, 2 * int(-(-n // 1024)))   # nodes per tile: >= 512 tiles
-        per = min(per, 62)
-        count = -(-sizes // per)                                      # tiles per graph
-        total = int(count.sum())
-        if total == 0:
+        # the CSR is read back once per bound batch: a few KB, next to the flag word bind reads anyway
+        tl = message_tile_table(node.row_splits_host(), ptr.cpu().numpy(), self.B,
+                                per=int(os.environ.get("MPENGINE_PAINN_TILE_R", "0")) or None)
+        if tl is None:
             return None
-        graph = np.repeat(np.arange(len(sizes)), count)
-        first = np.cumsum(count) - count
-        k = np.arange(total) - np.repeat(first, count)
-        r_lo = ns[graph] + k * per
-        r_hi = np.minimum(r_lo + per, ns[graph + 1])
-        ptr_host = ptr.cpu().numpy().astype(np.int64)
-        table = np.zeros((total, 8), dtype=np.int32)
-        table[:, 0], table[:, 1], table[:, 2], table[:, 3] = r_lo, r_hi, ns[graph], ns[graph + 1]
-        table[:, 4], table[:, 5] = ptr_host[r_lo], ptr_host[r_hi]
-        max_rows, max_edges = int(sizes.max()), int((table[:, 5] - table[:, 4]).max())
-        lds = ctypes.c_size_t(0)
-        _ffi.call("mp_painn_message_tiles_lds_bytes", max_rows, max_edges, self.B, 1, ctypes.byref(lds))
-        # the reverse kernel stages g_ds (F) + g_dv (3F) per node and two basis tables per edge: never more than this
-        if lds.value + max_edges * 4 * (self.B + 1) > 160 * 1024:
-            return None
-        return {"table": torch.from_numpy(table).to(node.values.device), "count": total, "max_rows": max_rows,
-                "max_edges": max_edges}
+        tl["table"] = torch.from_numpy(tl["table"]).to(node.values.device)
+        return tl
 
     # ------------------------------------------------------------------------------------------------ launches
     @staticmethod
