@@ -325,6 +325,7 @@ def run_config2(args, d):
         line["cpu_baseline"] = cpu_baseline(batch, params, DEPTH)
     if fwd.model.fused is not None:
         fwd.model.fused.release()
+    args._placed_streams = list(fwd._streams) if slots > 1 else None   # the fresh-batch leg serves its calls on the same streams
     return line
 
 
@@ -453,7 +454,8 @@ def run_stream(args, d, batches=64, in_flight=4):
         edges.append(int(b["edge_splits"][-1]))
     model = Schnet.make_model(depth=DEPTH)
     model.set_weights(list(synth.schnet_params(seed=7).values()))
-    streams = [torch.cuda.Stream() for _ in range(in_flight)]
+    placed = getattr(args, "_placed_streams", None)
+    streams = placed[:in_flight] if placed and len(placed) >= in_flight else [torch.cuda.Stream() for _ in range(in_flight)]
     packer = BatchPacker(items, index_item="edge_indices", node_item="node_number", slots=2 * in_flight)
 
     def as_inputs(pb):
