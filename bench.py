@@ -252,9 +252,15 @@ def run_config2(args, d):
     params = synth.schnet_params(seed=7)  # Keras defaults: glorot_uniform kernels, zero biases, U(-0.05, 0.05) embedding
     n_nodes, n_edges, n_graphs = int(batch["node_splits"][-1]), int(batch["edge_splits"][-1]), args.graphs
 
-    fwd = SchnetForward(params, depth=DEPTH, mode=args.mode, in_flight=args.in_flight)
+    # default: launch groups of 5 batches, 4 groups in flight (sweep in DESIGN section 5); an explicit --in-flight without
+    # --group keeps single batches
+    group = args.group if args.group else (5 if args.in_flight is None else 1)
+    if world > 1:
+        group = 1                                  # N > 1 (weak scaling rehearsal): one forward + one all-gather per step
+    in_flight = args.in_flight if args.in_flight else 4
+    fwd = SchnetForward(params, depth=DEPTH, mode=args.mode, in_flight=in_flight, group=group)
     fwd.load_batch(batch)
-    slots = fwd.in_flight
+    slots, group = fwd.in_flight, fwd.group
     gathered = [torch.empty((world * n_graphs, 1), dtype=torch.float32, device="cuda") for _ in range(slots)] \
         if world > 1 else None
     host_parts = [torch.empty((n_graphs, 1)) for _ in range(world)] if (world > 1 and d.backend == "gloo") else None
@@ -272,7 +278,25 @@ def run_config2(args, d):
                 d.dist.all_gather(host_parts, out.cpu())                # rehearsal only
         return out
 
-    elapsed = _time_steps(d, step, args.warmup, args.steps)
+    def run_steps(n):
+        # exactly n forwards of 128-graph batches: n // group launch groups (`group` batches concatenated on the device and
+        # served by one launch sequence, route.call_group), the remainder as single forwards
+        full, rem = divmod(n, group)
+        for j in range(full):
+            fwd.replay_group(j)
+        for r in range(rem):
+            fwd.replay(r, restore_stream=False)
+
+    if group > 1:
+        run_steps(args.warmup)
+        d.barrier()
+        t0 = time.perf_counter()
+        run_steps(args.steps)
+        torch.cuda.set_stream(torch.cuda.default_stream())
+        d.barrier()
+        elapsed = d.reduce(time.perf_counter() - t0, "MAX")
+    else:
+        elapsed = _time_steps(d, step, args.warmup, args.steps)
     total_edges = d.reduce(float(n_edges), "SUM")
     fwd.check_flags()
     # latency of ONE model(inputs) call with nothing else on the GPU (batch 0 alone), beside the throughput
@@ -309,9 +333,15 @@ def run_config2(args, d):
                                "graphs per GPU, N=%d nodes, M=%d directed edges on rank 0"
                                % (n_graphs, n_nodes, n_edges),
                    "graphs_per_gpu": n_graphs, "nodes": n_nodes, "edges": n_edges, "mode": fwd.mode,
-                   "in_flight": slots, "api": "gcnn_keras_amd.literature.Schnet.make_model(depth=3)(inputs)",
-                   "step": "one model(inputs) call on one batch; %d independent batches (own tensors, batch slot and HIP "
-                           "stream) are in flight, so kernels of different batches share the GPU" % slots,
+                   "in_flight": slots, "batches_per_launch_group": group,
+                   "api": "gcnn_keras_amd.literature.Schnet.make_model(depth=3)(inputs)" if group == 1 else
+                          "Schnet.make_model(depth=3).fused.call_group([inputs_1, ..., inputs_%d])" % group,
+                   "step": ("one model(inputs) call on one batch; %d independent batches (own tensors, batch slot and HIP "
+                            "stream) are in flight, so kernels of different batches share the GPU" % slots) if group == 1 else
+                           ("one forward of one %d-graph batch; %d independent batches (own tensors each) are served per "
+                            "launch sequence - concatenated on the device by one kernel, then the eight fused kernels on "
+                            "the union - and %d such groups are in flight on their own streams; K steps = K // %d group "
+                            "launches + K %% %d single forwards" % (n_graphs, group, slots, group, group)),
                    "sharding": "by graph, 1 all-gather of predictions per step" if world > 1 else "single GPU"},
         "single_forward_latency_ms": latency_ms,
         "stream_placement": fwd.placement,   # in-flight streams: best of the draws is used; a random draw gives the median
@@ -471,6 +501,22 @@ def run_stream(args, d, batches=64, in_flight=4):
                 model(as_inputs(pb))
     torch.cuda.synchronize()
     out = {"batches": batches, "graphs_per_batch": args.graphs, "in_flight": in_flight, "edges": int(sum(edges))}
+    # (b) with the host packer in the loop (run first: freeing the 64 resident batches of the other legs - device blocks that
+    #     were used on several streams - leaves the caching allocator with event bookkeeping that slows the next allocations)
+    results = []
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for k, g in enumerate(lists):
+        pb = packer.pack(g)
+        s = streams[k % in_flight]
+        with torch.cuda.stream(s):
+            pb.wait(s)
+            results.append(model(as_inputs(pb)))
+    torch.cuda.synchronize()
+    t_pack = time.perf_counter() - t0
+    out.update({"edges_per_s_with_host_packing": sum(edges) / t_pack, "ms_per_batch_with_host_packing": t_pack / batches * 1e3})
+    model.fused.release()
+    del results
     # (a) resident: everything packed and copied before the clock starts
     resident = [packer.pack(g) for g in lists[:2 * in_flight]]   # the packer's staging slots bound how many may be alive
     del resident
@@ -498,21 +544,34 @@ def run_stream(args, d, batches=64, in_flight=4):
     out.update({"edges_per_s_resident": sum(edges) / t_res, "ms_per_batch_resident": t_res / batches * 1e3,
                 "host_us_per_first_call_median": float(np.median(host_us)),
                 "host_us_per_first_call_p90": float(np.percentile(host_us, 90))})
-    del resident, results, packer_all
+    # (a') the same resident batches, served five per launch sequence (route.call_group: one concatenation launch + the
+    #      eight kernels for five never-seen batches instead of forty launches)
     model.fused.release()
-    # (b) with the host packer in the loop
+    grp = 5
+    for w in range(2):                                    # arena / allocator pools of the group-sized buffers
+        for k in range(0, 2 * grp * in_flight, grp):
+            torch.cuda.set_stream(streams[(k // grp) % in_flight])
+            model.fused.call_group(ins[k:k + grp])
+        torch.cuda.set_stream(base)
+        torch.cuda.synchronize()
+        model.fused.release() if w == 0 else None
+    model.fused._groups.clear()
     results = []
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    for k, g in enumerate(lists):
-        pb = packer.pack(g)
-        s = streams[k % in_flight]
-        with torch.cuda.stream(s):
-            pb.wait(s)
-            results.append(model(as_inputs(pb)))
+    for k in range(0, batches - batches % grp, grp):
+        torch.cuda.set_stream(streams[(k // grp) % in_flight])
+        results.extend(model.fused.call_group(ins[k:k + grp]))
+    for k in range(batches - batches % grp, batches):
+        results.append(model(ins[k]))
+    torch.cuda.set_stream(base)
     torch.cuda.synchronize()
-    t_pack = time.perf_counter() - t0
-    out.update({"edges_per_s_with_host_packing": sum(edges) / t_pack, "ms_per_batch_with_host_packing": t_pack / batches * 1e3})
+    t_grp = time.perf_counter() - t0
+    assert len(results) == batches and all(bool(torch.isfinite(r).all()) for r in results)
+    out.update({"edges_per_s_resident_grouped": sum(edges) / t_grp, "ms_per_batch_resident_grouped": t_grp / batches * 1e3,
+                "batches_per_launch_group": grp})
+    del resident, results, packer_all, ins
+    model.fused.release()
     model.fused.release()
     return out
 
@@ -528,9 +587,12 @@ def main():
     ap.add_argument("--graphs", type=int, default=128, help="config2: graphs per GPU (BASELINE config 2 = 128)")
     ap.add_argument("--total-graphs", type=int, default=100000, help="config4: molecules in the whole job")
     ap.add_argument("--mode", default="auto", choices=["auto", "fused", "layers"])
-    ap.add_argument("--in-flight", type=int, default=4,
-                    help="config2: independent batches (own tensors + batch slot + HIP stream) whose forwards overlap on "
-                         "the GPU; 1 = strictly one forward at a time")
+    ap.add_argument("--in-flight", type=int, default=None,
+                    help="config2: independent batches - or launch groups - (own tensors + batch slot + HIP stream) whose "
+                         "forwards overlap on the GPU; 1 = strictly one at a time; default 4")
+    ap.add_argument("--group", type=int, default=None,
+                    help="config2: independent batches served by ONE launch sequence (concatenated on the device, "
+                         "route.call_group); 1 = every batch its own model(inputs) call; default 5 (1 when --in-flight is given alone)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-stream", action="store_true",
                     help="skip the fresh-batch measurement (64 distinct batches, each called once) appended to the default line")
@@ -559,6 +621,7 @@ def main():
         if line is not None and d.world == 1 and args.workload == "auto" and not args.no_stream:
             fresh = run_stream(args, d)
             fresh["fraction_of_replay_value"] = fresh["edges_per_s_resident"] / line["value"]
+            fresh["grouped_fraction_of_replay_value"] = fresh["edges_per_s_resident_grouped"] / line["value"]
             line["stream_fresh_batches"] = fresh
         if line is not None and d.world == 1 and args.workload == "auto" and not args.no_config4_reference:
             ref = run_config4(args, d, standalone=False)

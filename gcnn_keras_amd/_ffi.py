@@ -137,6 +137,7 @@ _SIGNATURES = {
     "mp_host_free": [P, c_int],
     "mp_memcpy_h2d_async": [P, P, c_size_t, P],
     "mp_gcn_tile_f32": [P, P],
+    "mp_concat_batches": [P, P],
 }
 _RESTYPES = {"mp_last_error": c_char_p}
 
@@ -164,6 +165,21 @@ class SchnetForceDesc(ctypes.Structure):
                 + [(name, c_void_p) for name in ("Wl0T", "Wl1T", "seg0", "perm0", "seg1", "perm1", "ptr0", "ptr1",
                                                  "g_n", "g_agg", "g_x", "g_d", "force")]
                 + [("force_scale", c_float)])
+
+
+MP_CONCAT_MAX = 8
+
+
+class BatchSrc(ctypes.Structure):
+    """``mp_batch_src`` of include/mpengine.h."""
+    _fields_ = [(name, c_void_p) for name in ("z", "xyz", "idx", "node_splits", "edge_splits")] + \
+               [("N", c_int64), ("M", c_int64), ("G", c_int64)]
+
+
+class ConcatDesc(ctypes.Structure):
+    """``mp_concat_desc`` of include/mpengine.h (field for field)."""
+    _fields_ = [("k", ctypes.c_int32), ("z_is_i64", ctypes.c_int32), ("src", BatchSrc * MP_CONCAT_MAX)] + \
+               [(name, c_void_p) for name in ("z", "xyz", "idx", "node_splits", "edge_splits")]
 
 
 class GcnLayerDesc(ctypes.Structure):

@@ -55,7 +55,7 @@ class SchnetForward:
     the kernels of different batches share CUs: ``replay(i)`` is ``model(inputs[i % in_flight])`` on stream
     ``i % in_flight``."""
 
-    def __init__(self, params, depth=3, mode="auto", units=128, bins=20, gauss_args=None, in_flight=1):
+    def __init__(self, params, depth=3, mode="auto", units=128, bins=20, gauss_args=None, in_flight=1, group=1):
         from .literature import Schnet
         if not torch.cuda.is_available():
             raise _ffi.EngineError("SchnetForward needs an MI355X (no CPU fallback)")
@@ -77,6 +77,10 @@ class SchnetForward:
         self._slots = []
         self.placement = None
         self.in_flight = max(1, int(in_flight)) if mode == "fused" else 1
+        # launch groups: `group` independent batches served by ONE launch sequence (route.call_group: concatenated on the
+        # device), `in_flight` such groups in flight on their own streams
+        self.group = max(1, int(group)) if mode == "fused" else 1
+        self._group_inputs = []
         # several forwards in flight use the same 4-wave cfconv build as a lone forward (flag bit 4 - the 8-wave build,
         # two waves per SIMD on one LDS image - measured equal within run-to-run spread: 634 vs 621 M edges/s, and it
         # costs a lone forward 12 us); MPENGINE_INFLIGHT_CFCONV_FLAGS overrides for experiments
@@ -120,6 +124,22 @@ class SchnetForward:
                 self.model(self._inputs[k])   # binds the batch slot (index pass, buffers), direct launch
                 self.model(self._inputs[k])   # captures the slot's graph now, outside any timed region
             self._slots.append(self.model.fused.slot_of(self._inputs[k]))
+        if self.group > 1:
+            self.model.fused.max_groups = max(self.model.fused.max_groups, self.in_flight)
+            self._group_inputs = []
+            for k in range(self.in_flight):
+                members = []
+                for _ in range(self.group):        # every member is its own set of tensors, as different batches would be
+                    own = {key: (v.clone() if torch.is_tensor(v) else v) for key, v in self._batch.items()}
+                    members.append(self._ragged_inputs(own))
+                self._group_inputs.append(members)
+            torch.cuda.synchronize()
+            for k in range(self.in_flight):
+                with torch.cuda.stream(self._streams[k]):
+                    self.model.fused.call_group(self._group_inputs[k])    # bind + direct launch
+                    self.model.fused.call_group(self._group_inputs[k])    # capture, outside any timed region
+                    self.model.fused.call_group(self._group_inputs[k])
+                    self.model.fused.call_group(self._group_inputs[k])    # (the result ring's further executables)
         torch.cuda.synchronize()
         if self.in_flight > 1:
             self._place_streams()
@@ -133,13 +153,17 @@ class SchnetForward:
         outside any timed region."""
         import time
 
+        one = self.replay_group if self.group > 1 else self.replay
+        if self.group > 1:
+            steps = max(steps // self.group, 4 * self.in_flight)
+
         def rate():
             for i in range(2 * self.in_flight):
-                self.replay(i)
+                one(i)
             torch.cuda.synchronize()
             t0 = time.perf_counter()
             for i in range(steps):
-                self.replay(i)
+                one(i)
             torch.cuda.synchronize()
             return time.perf_counter() - t0
 
@@ -153,8 +177,9 @@ class SchnetForward:
         self._streams = best_streams
         seen.sort()
         # what a caller who simply takes four streams from torch's pool gets is a random draw: the median beside the best
-        self.placement = {"draws": draws, "steps_per_draw": steps, "best_us_per_step": seen[0] * 1e6,
-                          "median_us_per_step": seen[len(seen) // 2] * 1e6, "worst_us_per_step": seen[-1] * 1e6}
+        per = 1e6 / self.group            # a group launch is `group` steps
+        self.placement = {"draws": draws, "steps_per_draw": steps * self.group, "best_us_per_step": seen[0] * per,
+                          "median_us_per_step": seen[len(seen) // 2] * per, "worst_us_per_step": seen[-1] * per}
         torch.cuda.synchronize()
 
     @staticmethod
@@ -195,6 +220,13 @@ class SchnetForward:
             torch.cuda.set_stream(self._streams[k])
             return self.model(self._inputs[k])
         return self.forward(step)
+
+    def replay_group(self, j=0):
+        """Launch group ``j % in_flight`` on its stream: ``group`` forwards from one launch sequence (``route.call_group``);
+        torch's current stream stays that stream (a serving loop: the caller switches back when it is done)."""
+        k = j % self.in_flight
+        torch.cuda.set_stream(self._streams[k])
+        return self.model.fused.call_group(self._group_inputs[k])
 
     @property
     def stream(self):

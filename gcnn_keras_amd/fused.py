@@ -206,6 +206,7 @@ class FusedSchnet:
         self._b = None
         self._work = self._arena = None
         self._foreign_stream = False
+        self._pre = None            # launch group: the concatenation of the member batches runs in front of every forward
 
     @property
     def stream(self):
@@ -288,6 +289,8 @@ class FusedSchnet:
         # One linear chain on one stream.  (A two-branch graph - node_in beside edge_prepare - was measured 9 % SLOWER
         # at config 2: the fork/join costs more than the ~5 us of overlap it buys.)
         p, b, w = self.p, self._b, self.node_images
+        if self._pre is not None:
+            self._pre()
         if self.sorted or self.M == 0:
             # stage 0: node-input chain and edge preparation in one launch (independent work on disjoint workgroups)
             _ffi.call("mp_schnet_stage0_f32", _ffi.ptr(b["z"]), self.N, _ffi.ptr(p["embedding"]),
@@ -417,6 +420,8 @@ class FusedSchnet:
         elif how == "direct" and (self.sorted or self.M == 0) and self.depth <= _ffi.MP_SCHNET_MAX_DEPTH:
             if self._desc is None:
                 self._desc = self._descriptor()
+            if self._pre is not None:
+                self._pre()
             _ffi.call("mp_schnet_forward_launch", ctypes.byref(self._desc), _ffi.stream())
         else:
             self._launch_all()
@@ -585,6 +590,80 @@ class FusedSchnet:
             pass
 
 
+class SchnetGroup:
+    """A launch group: k bound batches served by ONE launch sequence.  The members' tensors are concatenated on the device
+    (``mp_concat_batches``: one launch, ~0.5 MB per 128-graph member) into this group's own union batch, on which an
+    ordinary batch slot runs; results are views of one fresh ``(sum G, 1)`` tensor, cut at the members' own row counts.
+    Graphs of a disjoint batch do not interact, so every member gets the rows a forward of its own would give (up to the
+    rounding order of the cfconv boundary sums, whose tile boundaries move: ~1e-6 relative)."""
+
+    def __init__(self, route, inputs_list):
+        k = len(inputs_list)
+        if not 1 <= k <= _ffi.MP_CONCAT_MAX:
+            raise ValueError("a launch group holds 1..%d batches" % _ffi.MP_CONCAT_MAX)
+        self.members = [tuple(x) for x in inputs_list]          # keeps the member tensors (and their addresses) alive
+        z0 = inputs_list[0][0].values
+        if any(x[0].values.dtype != z0.dtype for x in inputs_list):
+            raise ValueError("the members of a launch group must share the node-number dtype")
+        ns_host = [np.asarray(x[0].row_splits_host(), dtype=np.int64) for x in inputs_list]
+        sizes = [(int(x[0].values.shape[0]), int(x[2].values.shape[0]), x[0].nrows()) for x in inputs_list]
+        n, m, g = (sum(t[i] for t in sizes) for i in range(3))
+        dev = z0.device
+        self.z = torch.empty(n, dtype=z0.dtype, device=dev)
+        self.xyz = torch.empty((n, 3), dtype=torch.float32, device=dev)
+        self.idx = torch.empty((m, 2), dtype=torch.int64, device=dev)
+        self.ns = torch.empty(g + 1, dtype=torch.int64, device=dev)
+        self.es = torch.empty(g + 1, dtype=torch.int64, device=dev)
+        d = _ffi.ConcatDesc()
+        d.k, d.z_is_i64 = k, 1 if z0.dtype == torch.int64 else 0
+        for b, (x, (nb, mb, gb)) in enumerate(zip(inputs_list, sizes)):
+            node, xyz, idx = x
+            src = d.src[b]
+            src.z, src.xyz, src.idx = node.values.data_ptr(), xyz.values.data_ptr(), idx.values.data_ptr()
+            src.node_splits, src.edge_splits = node.row_splits.data_ptr(), idx.row_splits.data_ptr()
+            src.N, src.M, src.G = nb, mb, gb
+        d.z, d.xyz, d.idx = self.z.data_ptr(), self.xyz.data_ptr(), self.idx.data_ptr()
+        d.node_splits, d.edge_splits = self.ns.data_ptr(), self.es.data_ptr()
+        self.desc, self._desc_ref = d, ctypes.byref(d)
+        # host node splits of the union (row counts of the members: graphs without nodes at a member's end are dropped
+        # from ITS result, as its own forward would do)
+        offs, cat = 0, [np.zeros(1, np.int64)]
+        self.cuts = []
+        g_off = 0
+        for h, (nb, mb, gb) in zip(ns_host, sizes):
+            cat.append(h[1:] + offs)
+            rows = gb
+            while rows > 0 and h[rows] == h[rows - 1]:
+                rows -= 1
+            self.cuts.append((g_off, g_off + rows))
+            offs += nb
+            g_off += gb
+        known = 0
+        for x in inputs_list:           # every member's index list classified by its producer, or the union is checked below
+            flags = None
+            for plan in x[2]._plans.values():
+                if plan._flags_host is not None:
+                    flags = plan._flags_host
+            known = None if (known is None or flags is None) else (known | int(flags))
+        self.concat()
+        self.slot = FusedSchnet(route._p, depth=route.depth, gauss_args=route.gauss, fast_softplus=route.fast_softplus,
+                                cfconv_flags=route.cfconv_flags, packed=route._packed)
+        batch = {"z": self.z, "xyz": self.xyz, "idx": self.idx, "ns": self.ns, "es": self.es,
+                 "ns_host": np.concatenate(cat)}
+        self.slot.bind(batch, n, m, g, known_flags=known, arena=route._arena)
+        self.slot._pre = self.concat
+        self.slot.calls = 0
+        self.edges = m
+
+    def concat(self):
+        _ffi.check(_ffi.lib().mp_concat_batches(self._desc_ref, _ffi.stream()))
+
+    def split(self, out):
+        """Member results as views of the union's (rows, 1) result."""
+        full = int(out.shape[0])
+        return [out[lo:min(hi, full)] for lo, hi in self.cuts]
+
+
 class SchnetFusedRoute:
     """The fused forward behind ``Schnet.make_model(...)(inputs)``.
 
@@ -606,6 +685,8 @@ class SchnetFusedRoute:
         self.copy_output = True
         self._slots = {}
         self._gslots = {}           # batch slots of the energy + force pass (fused_schnet_force.FusedSchnetForce)
+        self._groups = {}           # launch groups (call_group): k bound batches served by one launch sequence
+        self.max_groups = 4
         self._p = None
         self._wkey = None
         self._wlist, self._vsum, self._wcalls, self._wepoch = None, 0, 0, -1
@@ -659,6 +740,7 @@ class SchnetFusedRoute:
         if moved:                  # other tensors: every bound slot (descriptor, graph) points at the old ones
             self._slots.clear()
             self._gslots.clear()
+            self._groups.clear()
             self._arena.clear()    # cached descriptors hold the old weight addresses
             self._grad_images = None
             self._p = {k: v for k, v in p.items() if v is not None}
@@ -720,6 +802,41 @@ class SchnetFusedRoute:
             return slot.hand_out_static()   # first sight: the slot's result buffer becomes the caller's tensor, no copy
         return out.clone()
 
+    def call_group(self, inputs_list):
+        """``[model(x) for x in inputs_list]`` from ONE launch sequence (``SchnetGroup``): the batches are concatenated on the
+        device and run as one union batch - the eight kernel boundaries and the weight staging are paid once for all of
+        them.  First call of a group: concatenation + direct launch; later calls replay the group's HIP graph (the
+        concatenation is part of it, so new coordinate values in the members' tensors are picked up).  Returns one tensor
+        per member, views of a result buffer nobody else holds.  Members must be receiver-sorted batches the route
+        accepts; anything else falls back to separate calls."""
+        inputs_list = [list(x) for x in inputs_list]
+        if len(inputs_list) == 1 or not all(self.accepts(x) for x in inputs_list):
+            return [self(x) for x in inputs_list]
+        self._sync_weights()
+        key = tuple(self._key(*x) for x in inputs_list)
+        grp = self._groups.get(key)
+        if grp is None:
+            grp = SchnetGroup(self, inputs_list)
+            while len(self._groups) >= self.max_groups:
+                self._groups.pop(next(iter(self._groups)))
+            self._groups[key] = grp
+        elif next(reversed(self._groups)) != key:
+            self._groups[key] = self._groups.pop(key)
+        slot = grp.slot
+        if not slot.sorted:              # the union of unsorted members: the separate route handles those
+            del self._groups[key]
+            return [self(x) for x in inputs_list]
+        slot.calls += 1
+        how = self.mode
+        if how == "auto":
+            how = "direct" if slot.calls == 1 else "graph"
+        self.last = how
+        if how == "graph":
+            out = slot.run_graph_fresh()
+            if out is not None:
+                return grp.split(out)
+        return grp.split(slot.run_current(how).clone())
+
     def energy_force(self, inputs):
         """``(energy (G', 1), force (N, 3))`` with force = -dE/dx: fused forward + hand-written reverse pass, one HIP
         graph per bound batch (gcnn_keras_amd/fused_schnet_force.py)."""
@@ -758,7 +875,7 @@ class SchnetFusedRoute:
         return self._slots.get(self._key(*inputs))
 
     def check_flags(self):
-        for slot in list(self._slots.values()) + list(self._gslots.values()):
+        for slot in list(self._slots.values()) + list(self._gslots.values()) + [g.slot for g in self._groups.values()]:
             slot.check_flags()
 
     def release(self):
@@ -766,5 +883,6 @@ class SchnetFusedRoute:
         torch.cuda.synchronize()
         self._slots.clear()
         self._gslots.clear()
+        self._groups.clear()
         self._arena.clear()
         self._wlist = None

@@ -477,6 +477,24 @@ typedef struct mp_schnet_forward_desc {
 } mp_schnet_forward_desc;
 int mp_schnet_forward_launch(const mp_schnet_forward_desc* desc_host, mpStream_t stream);
 
+/* ---------------------------------------------------------------- launch groups ------------------------------ */
+/* Disjoint union of k resident ragged batches in one launch (the device-side form of concatenating what two
+ * MemoryGraphList.tensor() calls produce, kgcnn/data/base.py:203-239): node numbers (float32, or int64 with z_is_i64),
+ * coordinates (N,3), edge sample indices (M,2) int64 - unchanged, kgcnn/layers/base.py:27 - and the two row-split arrays,
+ * rebased.  Outputs sized for the sums; node_splits / edge_splits get sum(G) + 1 entries.  Lets one launch sequence of the
+ * fused forward serve several independent batches (gcnn_keras_amd/fused.py::SchnetFusedRoute.call_group). */
+#define MP_CONCAT_MAX 8
+typedef struct mp_batch_src {
+  const void* z; const float* xyz; const int64_t* idx; const int64_t* node_splits; const int64_t* edge_splits;
+  int64_t N, M, G;
+} mp_batch_src;
+typedef struct mp_concat_desc {
+  int32_t k, z_is_i64;
+  mp_batch_src src[MP_CONCAT_MAX];
+  void* z; float* xyz; int64_t* idx; int64_t* node_splits; int64_t* edge_splits;
+} mp_concat_desc;
+int mp_concat_batches(const mp_concat_desc* desc_host, mpStream_t stream);
+
 /* ---------------------------------------------------------------- fused GCN forward -------------------------- */
 /* The forward of kgcnn.literature.GCN.make_model (kgcnn/literature/GCN.py:95-109) in 1 + depth launches on 16-node
  * tiles, each launch = one producer of the tile followed by up to three Keras Dense layers on it:

@@ -514,3 +514,81 @@ def test_model_call_returns_a_tensor_nobody_else_holds():
     seen = {model(inputs).data_ptr() for _ in range(8)}
     assert _ffi.launch_count() - before == 8 and len(seen) <= 3
     assert model.fused.last == "graph"
+
+
+def test_launch_group_serves_several_batches_from_one_launch_sequence():
+    """``route.call_group([inputs_a, inputs_b, ...])``: the members concatenated on the device (``mp_concat_batches``) and
+    run as one union batch - every member gets the rows of a forward of its own (graphs do not interact; the cfconv
+    boundary sums pair differently: 2e-6), against the oracle too; replayed from the group's graph on the second call,
+    following in-place coordinate updates of a member; a member that ends in a graph without nodes keeps its own row count."""
+    from gcnn_keras_amd.literature import Schnet
+    from helpers import dev
+    p = synth.schnet_params(seed=7, random_bias=True)
+    model = Schnet.make_model(depth=3)
+    model.set_weights(list(p.values()))
+    batches = [synth.qm9_like_batch(num_graphs=g, seed=s) for g, s in ((5, 1), (9, 2), (1, 3), (7, 4))]
+    b3 = batches[3]                                      # a trailing graph without nodes (and edges) in the last member ...
+    b3["node_splits"] = np.concatenate([b3["node_splits"], b3["node_splits"][-1:]])
+    b3["edge_splits"] = np.concatenate([b3["edge_splits"], b3["edge_splits"][-1:]])
+    b1 = batches[1]                                      # ... and in a middle one
+    b1["node_splits"] = np.concatenate([b1["node_splits"], b1["node_splits"][-1:]])
+    b1["edge_splits"] = np.concatenate([b1["edge_splits"], b1["edge_splits"][-1:]])
+    ins = [[dev(b["node_number"], b["node_splits"]), dev(b["node_coordinates"], b["node_splits"]),
+            dev(b["edge_indices"], b["edge_splits"])] for b in batches]
+
+    def oracle(b):
+        return ko.schnet_forward(p, ko.R(b["node_number"], b["node_splits"]), ko.R(b["node_coordinates"], b["node_splits"]),
+                                 ko.R(b["edge_indices"], b["edge_splits"]), depth=3)
+
+    alone = [model(x).cpu().numpy() for x in ins]
+    got = model.fused.call_group(ins)
+    assert model.fused.last == "direct" and len(got) == 4
+    again = model.fused.call_group(ins)
+    assert model.fused.last == "graph"
+    for k, b in enumerate(batches):
+        g_own = len(b["node_splits"]) - 1 - (1 if k in (1, 3) else 0)       # the member's own trailing empty graph dropped
+        assert tuple(got[k].shape) == (g_own, 1) == alone[k].shape
+        assert torch.equal(got[k], again[k])
+        assert rowwise_rel(got[k].cpu().numpy(), alone[k]) <= 2e-6
+        assert_rows_close(got[k].cpu().numpy(), oracle(b), what="launch group, member %d" % k)
+    # results are fresh tensors: a held result is not overwritten by the next call
+    keep = [t.clone() for t in again]
+    ins[2][1].values.mul_(1.01)                          # new coordinates for member 2 only
+    third = model.fused.call_group(ins)
+    for k in range(4):
+        assert torch.equal(again[k], keep[k])
+        assert torch.equal(third[k], keep[k]) == (k != 2)
+    batches[2]["node_coordinates"] = batches[2]["node_coordinates"] * np.float32(1.01)
+    assert_rows_close(third[2].cpu().numpy(), oracle(batches[2]), what="launch group, updated member")
+    model.fused.check_flags()
+
+
+def test_schnet_forward_harness_launch_groups_in_flight():
+    """``SchnetForward(group=k, in_flight=n)`` (what ``bench.py`` times by default): n launch groups of k independent batches
+    each; every member's rows equal a lone forward's (2e-6: the cfconv boundary sums pair differently in the union), the
+    groups overlap on their streams and return the same bits replay after replay."""
+    from gcnn_keras_amd.engine import SchnetForward
+    b = synth.qm9_like_batch(num_graphs=24, seed=5)
+    p = synth.schnet_params(seed=7, random_bias=True)
+    fwd = SchnetForward(p, depth=3, mode="fused", in_flight=2, group=3)
+    fwd.load_batch(b)
+    lone = fwd.forward(0).clone()
+    first = {}
+    for j in range(6):
+        outs = fwd.replay_group(j)
+        assert len(outs) == 3
+        if j < 2:
+            first[j] = [o.clone() for o in outs]
+    torch.cuda.set_stream(torch.cuda.default_stream())
+    torch.cuda.synchronize()
+    for j in range(2):
+        again = fwd.replay_group(j)
+        torch.cuda.synchronize()
+        for o, f in zip(again, first[j]):
+            assert torch.equal(o, f) and tuple(o.shape) == (24, 1)
+            assert rowwise_rel(o.cpu().numpy(), lone.cpu().numpy()) <= 2e-6
+    torch.cuda.set_stream(torch.cuda.default_stream())
+    ref = ko.schnet_forward(p, ko.R(b["node_number"], b["node_splits"]), ko.R(b["node_coordinates"], b["node_splits"]),
+                            ko.R(b["edge_indices"], b["edge_splits"]), depth=3)
+    assert_rows_close(first[0][1].cpu().numpy(), ref, what="launch group member through the harness")
+    fwd.check_flags()
