@@ -6,14 +6,15 @@ set -e
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 B="python3 bench.py --no-cpu-baseline --no-config4-reference --no-stream --steps 300"
 rocprofv3 --kernel-trace --stats -d gpurun_out/p3_c2_1 -o b -- $B --in-flight 1 > gpurun_out/p3_c2_1.log 2>&1
-rocprofv3 --kernel-trace --stats -d gpurun_out/p3_c2_4 -o b -- $B > gpurun_out/p3_c2_4.log 2>&1
+rocprofv3 --kernel-trace --stats -d gpurun_out/p3_c2_4 -o b -- $B --group 1 --in-flight 4 > gpurun_out/p3_c2_4.log 2>&1
+rocprofv3 --kernel-trace --stats -d gpurun_out/p3_grp -o b -- $B > gpurun_out/p3_grp.log 2>&1
 rocprofv3 --kernel-trace --stats -d gpurun_out/p3_stream -o b -- python3 bench.py --workload stream > gpurun_out/p3_stream.log 2>&1
 rocprofv3 --kernel-trace --stats -d gpurun_out/p3_pn_ef -o painn -- python3 scripts/profile_painn.py force 200 > gpurun_out/p3_pn_ef.log 2>&1
 rocprofv3 --kernel-trace --stats -d gpurun_out/p3_pn_f -o painn -- python3 scripts/profile_painn.py forward 200 > gpurun_out/p3_pn_f.log 2>&1
 rocprofv3 --kernel-trace --stats -d gpurun_out/p3_gcn -o gcn -- python3 scripts/profile_gcn.py 300 > gpurun_out/p3_gcn.log 2>&1
 rocprofv3 --kernel-trace --stats -d gpurun_out/p3_sf -o sf -- python3 scripts/bench_schnet_force.py 64 --profile fork 200 > gpurun_out/p3_sf.log 2>&1
 mkdir -p gpurun_out/stats
-for d in p3_c2_1 p3_c2_4 p3_stream p3_pn_ef p3_pn_f p3_gcn p3_sf; do
+for d in p3_c2_1 p3_c2_4 p3_grp p3_stream p3_pn_ef p3_pn_f p3_gcn p3_sf; do
   db=$(find gpurun_out/$d -name "*_results.db" | head -1)
   [ -n "$db" ] && python3 scripts/rocprof_db_stats.py $db gpurun_out/stats/$d.csv "$d" > /dev/null && rm -rf gpurun_out/$d
 done
