@@ -246,6 +246,14 @@ class SchnetForward:
         """Dominant kernel of the forward, timed live with HIP events on the stream it is launched on."""
         if self.mode == "fused":
             self.num_launches = self._fused.num_launches
+            if self.group > 1:      # the kernel as it runs in the timed loop: on the union of a launch group's members
+                route = self.model.fused
+                grp = route._groups.get(tuple(route._key(*x) for x in self._group_inputs[0]))
+                if grp is not None:
+                    roof = grp.slot.roofline(hbm_peak_gbs, mfma_peak_tf, iters)
+                    roof["kernel"] += " on the union of %d batches (%d edges, %d edge tiles)" % (
+                        self.group, grp.slot.M, (grp.slot.M + 31) // 32)
+                    return roof
             return self._fused.roofline(hbm_peak_gbs, mfma_peak_tf, iters)
         # layers mode: the per-edge filter GEMM (M,128)x(128,128) of SchNetCFconv.lay_dense2 dominates
         m, f = self.M, self.units

@@ -1,5 +1,6 @@
 """Merge fresh --pmc passes (scripts/run_pmc_gcn.sh: gpurun_out/pmc3_gcn_{fetch,write}, pmc2_{fetch,write}) into
-profiles/r02_pmc_hbm_traffic.json: entries with the same label are replaced, the others kept.
+profiles/r03_pmc_hbm_traffic.json (round 3: + the launch-group run, scripts/run_pmc_groups.sh): entries with the same
+label are replaced, the others kept.
 
     python scripts/merge_pmc.py
 """
@@ -11,7 +12,7 @@ import os
 import statistics
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-OUT = os.path.join(ROOT, "profiles", "r02_pmc_hbm_traffic.json")
+OUT = os.path.join(ROOT, "profiles", "r03_pmc_hbm_traffic.json")
 
 
 def short(name):
@@ -24,8 +25,16 @@ def agg(d):
              + glob.glob(os.path.join(ROOT, "gpurun_out", d, "*counter_collection.csv")))
     acc = collections.defaultdict(list)
     if files:
-        for r in csv.DictReader(open(files[0])):
-            acc[short(r["Kernel_Name"])].append(float(r["Counter_Value"]))
+        rows = list(csv.DictReader(open(files[0])))
+        biggest = collections.defaultdict(int)
+        for r in rows:
+            biggest[short(r["Kernel_Name"])] = max(biggest[short(r["Kernel_Name"])], int(r["Grid_Size"]))
+        for r in rows:
+            k = short(r["Kernel_Name"])
+            # a launch-group run also issues single-batch launches of the same kernels: only the union launches count
+            if "_grp_" in d and int(r["Grid_Size"]) != biggest[k]:
+                continue
+            acc[k].append(float(r["Counter_Value"]))
     return acc
 
 
@@ -44,6 +53,8 @@ def entry(fetch_dir, write_dir, label):
 
 
 new = [entry("pmc2_fetch", "pmc2_write", "config 2 (128 graphs, N=2301, M=26190): bench.py --in-flight 1, forward"),
+       entry("pmc_grp_fetch", "pmc_grp_write", "config 2 groups (five 128-graph batches per launch sequence: 640 graphs, "
+             "N=11.5 k, M=131 k per launch): bench.py --in-flight 1 --group 5"),
        entry("pmc3_gcn_fetch", "pmc3_gcn_write", "config 5 (Cora-shaped graph, N=2708, M=13264, F=1433): "
              "scripts/profile_gcn.py, fused GCN forward")]
 new = [e for e in new if e["kernels"]]

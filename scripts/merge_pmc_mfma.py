@@ -18,6 +18,8 @@ import statistics
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 OUT = os.path.join(ROOT, "profiles", "r03_pmc_mfma.json")
 PASSES = [("pmc_mfma_c2", "config 2 (128 graphs, N=2301, M=26190): bench.py --in-flight 1, forward"),
+          ("pmc_mfma_grp", "config 2 groups (five 128-graph batches per launch sequence: 640 graphs, N=11.5 k, M=131 k per "
+                           "launch): bench.py --in-flight 1 --group 5"),
           ("pmc_mfma_shard", "12500 graphs (config-4 shard, N=225 k, M=2.56 M): bench.py --workload config4 --total-graphs 12500"),
           ("pmc_mfma_painn", "config 3 (PaiNN, 64 graphs, N=1344, M=20586): scripts/profile_painn.py force")]
 
@@ -28,12 +30,21 @@ def short(name):
 
 
 def collect(d):
+    """kernel -> counter -> values.  A launch-group run (directory name ending in "_grp") also issues single-batch launches
+    of the same kernels (latency loop, warm-up): only the launches with a kernel's LARGEST grid - the union launches - count."""
     files = (glob.glob(os.path.join(ROOT, "gpurun_out", d, "*", "*counter_collection.csv"))
              + glob.glob(os.path.join(ROOT, "gpurun_out", d, "*counter_collection.csv")))
     acc = collections.defaultdict(lambda: collections.defaultdict(list))
     for f in files[:1]:
-        for r in csv.DictReader(open(f)):
-            acc[short(r["Kernel_Name"])][r["Counter_Name"]].append(float(r["Counter_Value"]))
+        rows = list(csv.DictReader(open(f)))
+        biggest = collections.defaultdict(int)
+        for r in rows:
+            biggest[short(r["Kernel_Name"])] = max(biggest[short(r["Kernel_Name"])], int(r["Grid_Size"]))
+        for r in rows:
+            k = short(r["Kernel_Name"])
+            if d.endswith("_grp") and int(r["Grid_Size"]) != biggest[k]:
+                continue
+            acc[k][r["Counter_Name"]].append(float(r["Counter_Value"]))
     return acc
 
 
