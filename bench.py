@@ -3,22 +3,26 @@
 
     python bench.py --gpus N --steps K --warmup W            (N > 1: launched by torch.distributed.run, one rank per GPU)
 
-A step = one call ``model(inputs)`` of ``gcnn_keras_amd.literature.Schnet.make_model`` (the mirror of
-kgcnn.literature.Schnet.make_model: F=128, depth 3, Gauss(20, 4.0, 0.4), sum pooling) on a batch whose raw API inputs
-(float node numbers, float32 coordinates, int64 (M,2) sample indices, int64 row_splits) are resident in HBM when the
-clock starts; index preparation (shift, receiver/sender split), geometry, basis expansion, every interaction block,
-readout, output MLP and the copy of the (G,1) result into a fresh tensor are inside it.  The model routes such a call
-through its fused HIP kernels (8 launches, replayed from a HIP graph for a re-bound batch; gcnn_keras_amd/fused.py).
+A step = one forward of ``gcnn_keras_amd.literature.Schnet.make_model`` (the mirror of kgcnn.literature.Schnet.make_model:
+F=128, depth 3, Gauss(20, 4.0, 0.4), sum pooling) on ONE 128-graph batch whose raw API inputs (float node numbers, float32
+coordinates, int64 (M,2) sample indices, int64 row_splits) are resident in HBM when the clock starts; index preparation
+(shift, receiver/sender split), geometry, basis expansion, every interaction block, readout and output MLP are inside it,
+and every step's result is a fresh tensor.  The model routes such a forward through its fused HIP kernels (8 launches,
+replayed from a HIP graph for a re-bound batch; gcnn_keras_amd/fused.py).
 
 Workloads (``--workload``; default ``config2`` at N = 1 and ``config4`` at N > 1):
 
 * ``config2``  BASELINE config 2, the configuration the metric is quoted on: 128 QM9-shaped graphs (seed 1234 + rank:
   N=2301, M=26190 on rank 0).  One 128-graph forward cannot fill an MI355X (819 edge tiles for 1024 SIMDs, 144 node
-  tiles for 256 CUs), so the loop keeps ``--in-flight`` (default 4) independent batches - own tensors, own batch slot
-  inside the model, own HIP stream - busy: step i is one full ``model(inputs[i % 4])`` on stream i % 4; kernels of
-  different batches overlap on the GPU.  Exactly K forwards run inside the timed region; ``single_forward_latency_ms``
-  reports the latency of a lone forward beside the throughput.  With N > 1 (``--workload config2``) every rank owns its
-  own 128-graph batches and one all-gather of the (G,1) predictions follows every forward: weak scaling.
+  tiles for 256 CUs, eight kernel boundaries of ~4 us), so the loop serves independent batches - own tensors each - in
+  LAUNCH GROUPS: ``--group`` (default 5) batches are concatenated on the device by one kernel and run by one launch sequence
+  (``model.fused.call_group``; every member gets the rows a forward of its own gives), and ``--in-flight`` (default 4) such
+  groups overlap on their own HIP streams.  Exactly K forwards run inside the timed region: K // group group launches + K %
+  group single ``model(inputs)`` calls.  ``--group 1`` is round 2's mode (every batch its own ``model(inputs)`` call, four in
+  flight); ``single_forward_latency_ms`` reports the latency of a lone ``model(inputs)`` call beside the throughput, and
+  ``stream_fresh_batches`` the rate for batches that are seen ONCE (bind + direct launch, no replay).  With N > 1
+  (``--workload config2``) every rank owns its own 128-graph batches and one all-gather of the (G,1) predictions follows
+  every forward: weak scaling.
 * ``config4``  BASELINE config 4: 100 000 QM9-shaped molecules (seed 3456) cut into N contiguous shards balanced by edge
   count (gcnn_keras_amd/sharding.py); rank r builds the edge lists of shard r on its GPU (the engine's SetRange, the
   reference's rule), runs one forward per step on it - no exchange during the forward - and ONE RCCL all-gather returns
