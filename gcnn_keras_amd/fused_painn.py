@@ -161,6 +161,7 @@ class FusedPainn:
         self.graphs = {}
         self.rings = {}
         self.calls = 0
+        self._pre = None      # launch group: the concatenation of the member batches runs in front of every pass
 
     # ------------------------------------------------------------------------------------------------ binding
     def bind(self, node, xyz, idx, grad):
@@ -344,6 +345,8 @@ class FusedPainn:
                   _ffi.ptr(self.perm1), n, m, -1.0, _ffi.ptr(self.force), _ffi.stream())
 
     def _launch(self, with_forces):
+        if self._pre is not None:
+            self._pre()
         self._forward(with_forces)
         if with_forces:
             self._backward()
@@ -444,6 +447,7 @@ class PainnFusedRoute:
         self.copy_output = True
         self._slots, self._p, self._wkey, self._images = {}, None, None, None
         self._wlist, self._vsum, self._wcalls, self._wepoch = None, 0, 0, -1
+        self._groups, self.max_groups = {}, 4     # launch groups (call_group): k bound batches served by one launch sequence
         self.last = None
 
     @staticmethod
@@ -487,6 +491,7 @@ class PainnFusedRoute:
         torch.cuda.synchronize()
         if moved:
             self._slots.clear()
+            self._groups.clear()
             self._p = {k: v for k, v in p.items() if v is not None}
             self._images = make_images(self._p, self.depth, self.n_out)
         else:
@@ -540,6 +545,41 @@ class PainnFusedRoute:
         eng, force = slot.run_current(True, how)
         return (eng.clone(), force.clone()) if self.copy_output else (eng, force)
 
+    def call_group(self, inputs_list, with_forces=False):
+        """k independent batches from ONE launch sequence (``group.BatchUnion``: concatenated on the device by one kernel,
+        then the ordinary pipeline on the union, the concatenation inside the captured graph).  Returns a list of energies
+        ``(G_b', 1)`` - or of ``(energy, force (N_b, 3))`` pairs with ``with_forces`` - as views of result buffers nobody else
+        holds; every member gets the rows of a call of its own (graphs do not interact)."""
+        from .group import BatchUnion
+        inputs_list = [list(x) for x in inputs_list]
+        if len(inputs_list) == 1 or not all(self.accepts(x, with_forces=with_forces) for x in inputs_list):
+            one = self.energy_force if with_forces else self.__call__
+            return [one(x) for x in inputs_list]
+        if with_forces and not self.single_state:
+            raise ValueError("fused forces are built for one energy state")
+        self._sync_weights()
+        key = tuple(self._key(*x, with_forces) for x in inputs_list)
+        union = self._groups.get(key)
+        if union is None:
+            union = BatchUnion(inputs_list)
+            union.concat()                                    # the index plan of the union is made from its values at bind
+            while len(self._groups) >= self.max_groups:
+                self._groups.pop(next(iter(self._groups)))
+            self._groups[key] = union
+        elif next(reversed(self._groups)) != key:
+            self._groups[key] = self._groups.pop(key)
+        slot, how = self._slot(union.inputs, grad=with_forces)
+        slot._pre = union.concat
+        got = slot.run_graph_fresh(with_forces) if (how == "graph" and self.copy_output) else None
+        if got is None:
+            eng, force = slot.run_current(with_forces, how)
+            got = (eng.clone(), force.clone() if with_forces else None) if self.copy_output else (eng, force)
+        eng, force = got if isinstance(got, tuple) else (got, None)
+        energies = union.split_graphs(eng)
+        if not with_forces:
+            return energies
+        return list(zip(energies, union.split_nodes(force)))
+
     def slot_of(self, inputs, grad=False):
         return self._slots.get(self._key(*inputs, grad))
 
@@ -550,4 +590,5 @@ class PainnFusedRoute:
     def release(self):
         torch.cuda.synchronize()
         self._wlist = None
+        self._groups.clear()
         self._slots.clear()

@@ -78,6 +78,14 @@ def main():
             with torch.cuda.stream(streams[i % k]):
                 energy(ins[i % k])
         out["fused"]["forward_ms_%d_in_flight" % k] = timeit(stepf, 200) * 1e3
+    # launch groups: the four batches concatenated on the device and served by one launch sequence (route.call_group)
+    for _ in range(3):
+        energy.fused.call_group(ins, with_forces=True), energy.fused.call_group(ins)
+    torch.cuda.synchronize()
+    t_gf = timeit(lambda i: energy.fused.call_group(ins), 100) / 4
+    t_gef = timeit(lambda i: energy.fused.call_group(ins, with_forces=True), 100) / 4
+    out["fused"]["forward_ms_per_batch_in_a_group_of_4"] = t_gf * 1e3
+    out["fused"]["energy_force_ms_per_batch_in_a_group_of_4"] = t_gef * 1e3
     if with_layers:
         force.fused = False
         g_f = GraphedModel(lambda x: energy(x, fused=False), ins[0], grad=False)
@@ -86,6 +94,7 @@ def main():
                                           "energy_force_ms": timeit(lambda i: g_ef(), 50) * 1e3}
         force.fused = None
     # kernel classes, timed alone with HIP events on the stream they are launched on
+    force(ins[0])                            # (the group's union may have taken this batch's place in the slot table)
     slot = energy.fused.slot_of(ins[0], grad=True)
     p, w, blk = slot.p, slot.w, slot.blk[1]
     timer = _HipTimer()

@@ -191,3 +191,39 @@ def _edges_by_rule(b, max_distance=5.0):
         es.append(synth.radius_graph(b["node_coordinates"][ns[g]:ns[g + 1]], max_distance, 10000))
     return {"edge_indices": np.concatenate(es).astype(np.int64).reshape(-1, 2),
             "edge_splits": np.concatenate([[0], np.cumsum([len(e) for e in es])]).astype(np.int64)}
+
+
+def test_painn_launch_group_energy_and_forces():
+    """``route.call_group([...], with_forces=True)``: three independent batches (different sizes) concatenated on the device
+    and served by one launch sequence - energies and every atom's force of every member against the oracle / the analytic
+    reference, equal (2e-6 / same force bars) to calls of their own, replayed bit-identically, following an in-place
+    coordinate update of one member.  (Member seeds: batches whose float32 oracle is itself within 1e-5 of its float64 twin -
+    a molecule whose atom contributions cancel carries float32 noise of several 1e-5 in all three float32 pipelines, engine,
+    layer path and oracle alike: scripts/diag_painn_energy_noise.py, 30 seeds, medians 7.5e-7 / 9.4e-7 / 8.4e-7.)"""
+    p = synth.painn_params(seed=8, random_bias=True)
+    energy = _model(p)
+    batches = [synth.md17_like_batch(num_graphs=g, seed=s) for g, s in ((3, 21), (5, 22), (2, 23))]
+    ins = [mol_inputs(b) for b in batches]
+    alone = [energy.fused.energy_force(x) for x in ins]
+    got = energy.fused.call_group(ins, with_forces=True)
+    assert energy.fused.last == "eager" and len(got) == 3
+    again = energy.fused.call_group(ins, with_forces=True)
+    assert energy.fused.last == "graph"
+    for k, b in enumerate(batches):
+        (e, f), (e2, f2), (ea, fa) = got[k], again[k], alone[k]
+        assert torch.equal(e, e2) and torch.equal(f, f2)
+        assert tuple(e.shape) == (len(b["node_splits"]) - 1, 1) and tuple(f.shape) == (int(b["node_splits"][-1]), 3)
+        assert rowwise_rel(e.cpu().numpy(), ea.cpu().numpy()) <= 2e-6
+        assert_rows_close(e.cpu().numpy(), _oracle(p, b), _oracle(p, b, np.float64), what="PaiNN group energy, member %d" % k)
+        f32, f64 = _reference_forces(p, b)
+        assert_forces_close(f.cpu().numpy(), f32, f64, b["node_splits"], what="PaiNN group forces, member %d" % k)
+    fwd_only = energy.fused.call_group(ins)
+    for k in range(3):
+        assert rowwise_rel(fwd_only[k].cpu().numpy(), got[k][0].cpu().numpy()) <= 2e-6
+    ins[1][1].values.add_(0.01)                                        # member 1 moves; the graph re-concatenates
+    batches[1]["node_coordinates"] = batches[1]["node_coordinates"] + np.float32(0.01)
+    moved = energy.fused.call_group(ins, with_forces=True)
+    assert torch.equal(moved[0][1], got[0][1]) and not torch.equal(moved[1][1], got[1][1])
+    f32, f64 = _reference_forces(p, batches[1])
+    assert_forces_close(moved[1][1].cpu().numpy(), f32, f64, batches[1]["node_splits"], what="PaiNN group forces after a move")
+    energy.fused.check_flags()
