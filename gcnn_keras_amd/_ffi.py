@@ -93,6 +93,9 @@ _SIGNATURES = {
     "mp_painn_message_tiles_lds_bytes": [c_int, c_int, c_int, c_int, P],
     "mp_painn_message_tiles_f32": [P, P, c_int64, P, c_int, P, P, P, P, P, c_int64, P, c_int, c_int, c_int, P, P, P, P],
     "mp_painn_message_bwd_f32": [P, P, c_int64, P, P, c_int, P, P, P, P, P, P, P, P, c_int64, P, P, P, P, P, P, c_int, P],
+    "mp_painn_message_bwd_tiles_lds_bytes": [c_int, c_int, c_int, c_int, c_int, P],
+    "mp_painn_message_bwd_tiles_f32": [P, P, c_int64, P, P, c_int, P, P, P, P, P, P, P, c_int64, P, c_int, c_int, c_int,
+                                       c_int, P, P, P, P, P, P, c_int, P],
     "mp_painn_update_pre_f32": [P, P, c_int64, P, P, P],
     "mp_painn_update_fused_f32": [P, P, P, c_int64, P, P, c_int, c_float, P, P, P, P, P, P, P, P, P],
     "mp_painn_update_fused_bwd_f32": [P, P, P, P, P, P, c_int64, P, c_int, c_float, P, P, P, P, P],

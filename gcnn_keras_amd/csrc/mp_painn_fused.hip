@@ -66,6 +66,87 @@ template <int CTRL>
 __device__ __forceinline__ float dpp_mov(float v) {
   return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xf, 0xf, true));
 }
+// LDS reads of DIFFERENT kinds (4-B, two-address, 16-B) in flight together are not safe behind a partial
+// `s_waitcnt lgkmcnt(N)` on this part: the consumer has been seen with the old register contents (the address the read was
+// issued with) in the lanes written last (48-63) - single edge contributions missing, different from run to run.  hipcc
+// assumes issue-order retirement: it consumes each value behind a partial wait of its own, merges 4-B reads into two-address
+// ones and copies loaded registers early, whatever `s_waitcnt` builtins, scheduling barriers or "+v" operand ties the source
+// puts after the loads.  So the mixed-width groups of the tile kernels are ONE asm statement each: the reads and a full
+// `lgkmcnt(0)` inside, results as early-clobber outputs - nothing can be consumed, merged or copied in between.  Uniform
+// groups (all 4-B, all 16-B) stay with the compiler.
+using floatx4 = __attribute__((ext_vector_type(4))) float;
+using bf16x8 = __attribute__((ext_vector_type(8))) __bf16;
+using floatx16 = __attribute__((ext_vector_type(16))) float;
+__device__ __forceinline__ unsigned lds_addr(const void* p) {
+  return static_cast<unsigned>(reinterpret_cast<size_t>((__attribute__((address_space(3))) const char*)p));
+}
+__device__ __forceinline__ void lds_wait_all() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
+// The tail of an MFMA burst is allowed to finish (64 idle cycles after the last issue; one 32x32x16 MFMA takes 32) before
+// the first LDS read that follows it: without this the reverse tile kernel lost single reads in lanes 48-63 (the register
+// kept what it held before - an operand piece of the burst), 1 call in 30 to every call depending on the build; with it
+// 500 of 500 calls are bit-identical (scripts/stress_painn_bwd.py).  The accumulators pass through the statement, so
+// neither the MFMAs nor the reads move across it.
+__device__ __forceinline__ void mfma_drained(floatx16 (&acc)[3]) {
+  asm volatile("s_nop 15\n\ts_nop 15\n\ts_nop 15\n\ts_nop 15" : "+v"(acc[0]), "+v"(acc[1]), "+v"(acc[2]));
+}
+// one edge of a group: three rows F floats apart at `rows` (+ one value at `one`, when ONE) + a 16-B entry at `entry`
+struct EdgeReads {
+  float a[3], b[3], one;
+  floatx4 e;
+};
+// forward: s_j (3 parts) at `sa`, v_j (3 components) at `va`, {r_ij, envelope} at `pa`, for two edges
+__device__ __forceinline__ void lds_group_fwd(unsigned sa0, unsigned va0, unsigned pa0, unsigned sa1, unsigned va1,
+                                              unsigned pa1, EdgeReads& x, EdgeReads& y) {
+  asm volatile(
+      "ds_read_b32 %0, %14\n\tds_read_b32 %1, %14 offset:512\n\tds_read_b32 %2, %14 offset:1024\n\t"
+      "ds_read_b32 %3, %15\n\tds_read_b32 %4, %15 offset:512\n\tds_read_b32 %5, %15 offset:1024\n\t"
+      "ds_read_b128 %6, %16\n\t"
+      "ds_read_b32 %7, %17\n\tds_read_b32 %8, %17 offset:512\n\tds_read_b32 %9, %17 offset:1024\n\t"
+      "ds_read_b32 %10, %18\n\tds_read_b32 %11, %18 offset:512\n\tds_read_b32 %12, %18 offset:1024\n\t"
+      "ds_read_b128 %13, %19\n\t"
+      "s_waitcnt lgkmcnt(0)"
+      : "=&v"(x.a[0]), "=&v"(x.a[1]), "=&v"(x.a[2]), "=&v"(x.b[0]), "=&v"(x.b[1]), "=&v"(x.b[2]), "=&v"(x.e),
+        "=&v"(y.a[0]), "=&v"(y.a[1]), "=&v"(y.a[2]), "=&v"(y.b[0]), "=&v"(y.b[1]), "=&v"(y.b[2]), "=&v"(y.e)
+      : "v"(sa0), "v"(va0), "v"(pa0), "v"(sa1), "v"(va1), "v"(pa1)
+      : "memory");
+}
+// reverse: g_z at `za`, g_dv (3 components) at `ga`, {r_ij, envelope} at `pa` (and envelope' at `ea`, when ENV), two edges
+template <bool ENV>
+__device__ __forceinline__ void lds_group_bwd(unsigned za0, unsigned ga0, unsigned pa0, unsigned ea0, unsigned za1,
+                                              unsigned ga1, unsigned pa1, unsigned ea1, EdgeReads& x, EdgeReads& y) {
+  if constexpr (ENV) {
+    asm volatile(
+        "ds_read_b32 %0, %12\n\tds_read_b32 %1, %13\n\tds_read_b32 %2, %13 offset:512\n\tds_read_b32 %3, %13 offset:1024\n\t"
+        "ds_read_b128 %4, %14\n\tds_read_b32 %5, %15\n\t"
+        "ds_read_b32 %6, %16\n\tds_read_b32 %7, %17\n\tds_read_b32 %8, %17 offset:512\n\tds_read_b32 %9, %17 offset:1024\n\t"
+        "ds_read_b128 %10, %18\n\tds_read_b32 %11, %19\n\t"
+        "s_waitcnt lgkmcnt(0)"
+        : "=&v"(x.one), "=&v"(x.b[0]), "=&v"(x.b[1]), "=&v"(x.b[2]), "=&v"(x.e), "=&v"(x.a[0]), "=&v"(y.one), "=&v"(y.b[0]),
+          "=&v"(y.b[1]), "=&v"(y.b[2]), "=&v"(y.e), "=&v"(y.a[0])
+        : "v"(za0), "v"(ga0), "v"(pa0), "v"(ea0), "v"(za1), "v"(ga1), "v"(pa1), "v"(ea1)
+        : "memory");
+  } else {
+    asm volatile(
+        "ds_read_b32 %0, %10\n\tds_read_b32 %1, %11\n\tds_read_b32 %2, %11 offset:512\n\tds_read_b32 %3, %11 offset:1024\n\t"
+        "ds_read_b128 %4, %12\n\t"
+        "ds_read_b32 %5, %13\n\tds_read_b32 %6, %14\n\tds_read_b32 %7, %14 offset:512\n\tds_read_b32 %8, %14 offset:1024\n\t"
+        "ds_read_b128 %9, %15\n\t"
+        "s_waitcnt lgkmcnt(0)"
+        : "=&v"(x.one), "=&v"(x.b[0]), "=&v"(x.b[1]), "=&v"(x.b[2]), "=&v"(x.e), "=&v"(y.one), "=&v"(y.b[0]), "=&v"(y.b[1]),
+          "=&v"(y.b[2]), "=&v"(y.e)
+        : "v"(za0), "v"(ga0), "v"(pa0), "v"(za1), "v"(ga1), "v"(pa1)
+        : "memory");
+    x.a[0] = 0.0f;
+    y.a[0] = 0.0f;
+  }
+}
+static_assert(F == 128, "the asm read groups address rows 512 B apart");
+
+// x[l] + x[l ^ 32] in every lane (lower half's value first)
+__device__ __forceinline__ float sum_halves(float x) {
+  const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(x), __float_as_uint(x), false, false);
+  return __uint_as_float(r[0]) + __uint_as_float(r[1]);
+}
 __device__ __forceinline__ float wave_sum_uniform(float v) {
   v += dpp_mov<0xB1>(v);    // quad_perm [1,0,3,2]
   v += dpp_mov<0x4E>(v);    // quad_perm [2,3,0,1]
@@ -350,8 +431,6 @@ __global__ __launch_bounds__(256) void painn_message_kernel(PainnMsgArgs a) {
 // zero A row (bias slot included), so their filter - and message - is exactly 0; their loads re-read a valid edge.
 // The weights Ww | bw are split into the wave's 18 B-operand registers x 4 once per wave (workgroups are persistent over
 // pairs); the basis rows are split per tile.
-using bf16x8 = __attribute__((ext_vector_type(8))) __bf16;
-using floatx16 = __attribute__((ext_vector_type(16))) float;
 
 __device__ __forceinline__ void split3_into(float x, bf16x8& hi, bf16x8& mid, bf16x8& lo, int i) {
   const __bf16 p0 = static_cast<__bf16>(x);
@@ -780,12 +859,13 @@ __global__ __launch_bounds__(256, 2) void painn_message_tile_kernel(PainnTileArg
           acc[p] = mfma_bf16x3(qa[0], wb[p][0], acc[p]);
           acc[p] = mfma_bf16x3(qa[1], wb[p][1], acc[p]);
         }
+        mfma_drained(acc);
         // messages in edge order.  LDS reads are issued in groups of two edges - the step's eight sender offsets first, then
-        // per group 2 x (3 + 3 + 1) = 14 read instructions at most - and each group is complete (lgkmcnt(0)) before its
-        // arithmetic.  The LGKM counter has four bits: with MORE than 15 LDS reads in flight behind partial waits, registers
-        // were consumed before their data had arrived (wrong v' components in lanes 48-63, varying from run to run, seen
-        // on the hardware with 72 reads in flight); read-next-to-use on the other hand exposes one LDS round trip per
-        // value.  Rows past the receiver's edge count have a zero filter; their reads repeat edge 0 of the tile.
+        // per group 2 x (3 + 3 + 1) = 14 read instructions - and each group is complete before its arithmetic: one asm
+        // statement with a full lgkmcnt(0) inside (lds_group_fwd; the note at its definition).  With the step's 72 reads
+        // issued up front behind partial waits, registers were consumed before their data had arrived (wrong v' components
+        // in lanes 48-63, varying from run to run); read-next-to-use on the other hand exposes one LDS round trip per value.  Rows past the
+        // receiver's edge count have a zero filter; their reads repeat edge 0 of the tile.
 #pragma unroll
         for (int bt = 0; bt < 16; bt += 8) {
           if (bt < maxc - cb) {     // wave-uniform
@@ -793,27 +873,26 @@ __global__ __launch_bounds__(256, 2) void painn_message_tile_kernel(PainnTileArg
 #pragma unroll
             for (int u = 0; u < 8; ++u) {
               le[u] = cb + bt + u < cnt ? own_lo + cb + bt + u : 0;
-              jb[u] = Sd[le[u]] + f0;                            // float offset of the sender's staged rows (made above)
+              jb[u] = Sd[le[u]];                                 // float offset of the sender's staged rows (made above)
             }
-            __builtin_amdgcn_sched_barrier(0);
-            __builtin_amdgcn_s_waitcnt(0xC07F);                   // lgkmcnt(0)
-            __builtin_amdgcn_sched_barrier(0);
+            lds_wait_all();                                       // eight 4-B reads: uniform
+            const unsigned ss_base = lds_addr(Ss) + 4u * f0, vs_base = lds_addr(Vs) + 4u * f0, p4_base = lds_addr(P4);
 #pragma unroll
             for (int g2 = 0; g2 < 8; g2 += 2) {
+              EdgeReads rd[2];
+              lds_group_fwd(ss_base + 4u * jb[g2], vs_base + 4u * jb[g2], p4_base + 16u * le[g2], ss_base + 4u * jb[g2 + 1],
+                            vs_base + 4u * jb[g2 + 1], p4_base + 16u * le[g2 + 1], rd[0], rd[1]);
               float sj[2][3], vj[2][3];
               float4 re[2];
 #pragma unroll
               for (int u = 0; u < 2; ++u) {
 #pragma unroll
                 for (int p = 0; p < 3; ++p) {
-                  sj[u][p] = Ss[jb[g2 + u] + p * F];
-                  vj[u][p] = Vs[jb[g2 + u] + p * F];
+                  sj[u][p] = rd[u].a[p];
+                  vj[u][p] = rd[u].b[p];
                 }
-                re[u] = P4[le[g2 + u]];
+                re[u] = make_float4(rd[u].e[0], rd[u].e[1], rd[u].e[2], rd[u].e[3]);
               }
-              __builtin_amdgcn_sched_barrier(0);
-              __builtin_amdgcn_s_waitcnt(0xC07F);                 // lgkmcnt(0): the group's reads are here
-              __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
               for (int u = 0; u < 2; ++u) {
                 const float rr[3] = {re[u].x, re[u].y, re[u].z};
@@ -1016,6 +1095,419 @@ __global__ __launch_bounds__(256) void painn_message_bwd_kernel(PainnMsgBwdArgs 
         const int64_t at = (static_cast<int64_t>(j) * 3 + k) * F + f0;
         a.g_v[at] = a.g_dv[at] + gv[k];
       }
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------- reverse, tile form
+// The reverse message step on SENDER tiles: a workgroup serves a few consecutive sending nodes of one graph, wave q the
+// feature quarter 32 q .. 32 q + 31.  Staged in LDS after ONE barrier: the upstream gradients g_ds / g_dv of the graph's
+// whole node range (the receivers of a tile's edges lie in its own graph) by contiguous LDS-DMA, the basis rows rbf_e and
+// rbf'_e of the tile's edges by GATHER LDS-DMA (per-lane source address through perm1: sender order is a permutation of
+// the stored edge order), receiver row / unit vector / envelope per edge by one thread per edge.
+//
+// Per sender and step of up to 16 edges one 32 x 32 filter tile per part on the matrix pipe (bf16x3, the forward kernel's
+// pre-split weight image): A row m = [rbf_e | 1] (m even) or [rbf'_e | 0] (m odd) of the edge in slot (m & 3) / 2 +
+// 2 (m >> 3) of lane half (m >> 2) & 1, so accumulator registers (2 u, 2 u + 1) of a lane hold the filter and its
+// derivative w.r.t. the distance for the lane's own feature and the edge `2 u + half` of the step: the two lane halves
+// walk the even and the odd edges of the step in register order.  dE/ds_j, dE/dv_j accumulate in registers (even / odd
+// partial sums added once per sender: fixed order, deterministic), the four per-edge scalars (dE/dd_e, dE/dr_ij) of the
+// step's slots are reduced over the 32 features of a lane half by a TRANSPOSING reduction (32 values per lane in, one
+// total per lane out: 16 + 8 + 4 + 2 + 1 exchange-adds instead of 32 x 5), parked per wave in LDS and summed over the four
+// waves in fixed order at the end of the tile.
+struct PainnBwdTileArgs {
+  const float* s;        // (N, 3F)   saved forward s
+  const float* v;        // (N, 3, F) saved block-input v
+  const float* rbf;      // (M, B)
+  const float* rbfd;     // (M, B)
+  const float* env;      // (M) or null
+  const float* envd;     // (M) or null
+  const float* rij;      // (M, 3)
+  const void* wimg;      // packed filter image (mp_painn_filter_pack_f32)
+  const int32_t* tiles;  // (T, 8): j_lo, j_hi, s_lo, s_hi, e_lo, e_hi (sender-order positions), -, -
+  const int32_t* ptr1;   // (N+1) CSR over senders
+  const int32_t* perm1;  // (M) sender-order position -> stored edge, or null
+  const int32_t* recv;   // (M) stored edge order
+  const float* g_ds;     // (N, F)
+  const float* g_dv;     // (N, 3, F)
+  float* g_s;            // (N, 3F)
+  float* g_v;            // (N, 3, F) or null
+  float* g_d;            // (M)    written (accumulate = 0) or added to
+  float* g_rij;          // (M, 3)
+  int accumulate;
+  int64_t N, M;
+  int B, ntiles, max_rows, max_senders, max_edges;
+};
+
+// k groups of 8 per A row held as bf16 pieces: k = 0 .. B (bias slot) -> ceil((B + 1) / 8)
+__host__ __device__ __forceinline__ int painn_kgroups(int B) { return (B + 8) >> 3; }
+__host__ __device__ __forceinline__ int painn_bwd_tile_lds_floats(int max_rows, int max_senders, int max_edges, int B,
+                                                                  bool env) {
+  return painn_pad(max_rows * F, 256) + painn_pad(max_rows * 3 * F, 256) + 2 * painn_pad(max_senders * 3 * F, 256) +
+         painn_pad((2 * max_edges * painn_kgroups(B) * 3 + 3) * 4, 64) + painn_pad(max_edges * 4, 64) +
+         (env ? painn_pad(max_edges, 64) : 0) + 2 * painn_pad(max_edges, 64) + painn_pad(4 * max_edges * 4, 64);
+}
+
+// x[l] + x[l ^ 16] for the lanes of even 16-lane rows, y[l] + y[l ^ 16] for the odd rows
+__device__ __forceinline__ float fold16(float x, float y) {
+  const auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(x), __float_as_uint(y), false, false);
+  return __uint_as_float(r[0]) + __uint_as_float(r[1]);
+}
+// lanes with `bit` clear: x[l] + x[partner]; lanes with it set: y[l] + y[partner] (partner = the DPP pattern's source)
+template <int CTRL>
+__device__ __forceinline__ float fold_dpp(bool bit, float x, float y) {
+  const float send = bit ? x : y, keep = bit ? y : x;
+  return keep + dpp_mov<CTRL>(send);
+}
+__device__ __forceinline__ float fold4(bool bit, float x, float y) {   // partner l ^ 4: row_shl:4 for banks 0, 2; row_shr:4 for 1, 3
+  const float send = bit ? x : y, keep = bit ? y : x;
+  int t = __builtin_amdgcn_update_dpp(0, __float_as_int(send), 0x104, 0xf, 0x5, false);
+  t = __builtin_amdgcn_update_dpp(t, __float_as_int(send), 0x114, 0xf, 0xA, false);
+  return keep + __int_as_float(t);
+}
+__device__ __forceinline__ float xor4_sum(float x) {                   // x[l] + x[l ^ 4]
+  int t = __builtin_amdgcn_update_dpp(0, __float_as_int(x), 0x104, 0xf, 0x5, false);
+  t = __builtin_amdgcn_update_dpp(t, __float_as_int(x), 0x114, 0xf, 0xA, false);
+  return x + __int_as_float(t);
+}
+// NV = 8, 16 or 32 values per lane -> every lane c of a 32-lane half holds the half's total of value
+// v(c) = bit4(c) + 2 bit3(c) + 4 bit2(c) [+ 8 bit1(c) [+ 16 bit0(c)]]: each exchange-add halves the number of live values
+// (NV - 1 of them instead of 5 NV); lane bits beyond log2(NV) are finished by plain butterflies.
+template <int NV>
+__device__ __forceinline__ float transpose_sum(const float (&val)[NV], int c) {
+  float w2[NV / 2], w4[NV / 4], w8[NV / 8];
+#pragma unroll
+  for (int i = 0; i < NV / 2; ++i) w2[i] = fold16(val[2 * i], val[2 * i + 1]);
+#pragma unroll
+  for (int i = 0; i < NV / 4; ++i) w4[i] = fold_dpp<0x128>((c & 8) != 0, w2[2 * i], w2[2 * i + 1]);   // row_ror:8
+#pragma unroll
+  for (int i = 0; i < NV / 8; ++i) w8[i] = fold4((c & 4) != 0, w4[2 * i], w4[2 * i + 1]);
+  if constexpr (NV == 8) {
+    float t = w8[0];
+    t += dpp_mov<0x4E>(t);                                               // quad_perm [2,3,0,1]
+    return t + dpp_mov<0xB1>(t);                                         // quad_perm [1,0,3,2]
+  } else {
+    float w16[NV / 16];
+#pragma unroll
+    for (int i = 0; i < NV / 16; ++i) w16[i] = fold_dpp<0x4E>((c & 2) != 0, w8[2 * i], w8[2 * i + 1]);
+    if constexpr (NV == 16) return w16[0] + dpp_mov<0xB1>(w16[0]);
+    else return fold_dpp<0xB1>((c & 1) != 0, w16[0], w16[1]);
+  }
+}
+
+// The messages of G groups of two slots (lane half hh: edge 2 u + hh of the step) from the filter tile `acc`, their
+// per-edge scalars reduced over the lane half and parked in `part` (this wave's slab, indexed by the tile's edge).
+template <int G, bool ENV>
+__device__ __forceinline__ void painn_bwd_slots(const floatx16 (&acc)[3], const float* Gz, const float* Gv, const float4* P4,
+                                                const float* Ed, const int* Sd, float4* part, int first_edge, int nh, int hh,
+                                                int c, int f0, const float (&sj)[3], const float (&vj)[3], float (&gs)[3],
+                                                float (&gv)[3]) {
+  constexpr int NS = G == 3 ? 8 : 2 * G;      // slots reduced (three groups use the four-group reduction, zeros on top)
+  float red[4 * NS];
+  int le[2 * G], ir[2 * G];
+#pragma unroll
+  for (int u = 0; u < 2 * G; ++u) {
+    le[u] = 2 * u + hh < nh ? first_edge + 2 * u + hh : 0;   // rows past the step: zero filter; reads repeat edge 0
+    ir[u] = Sd[le[u]];
+  }
+  lds_wait_all();                                             // 4-B reads only: uniform
+  const unsigned gz_base = lds_addr(Gz) + 4u * f0, gv_base = lds_addr(Gv) + 4u * f0, p4_base = lds_addr(P4),
+                 ed_base = ENV ? lds_addr(Ed) : 0u;
+#pragma unroll
+  for (int g2 = 0; g2 < 2 * G; g2 += 2) {
+    // the group's reads (4-B and 16-B) and their full wait as one statement
+    EdgeReads rd[2];
+    // (24-bit multiplies: the 64-bit multiply-add hipcc picks for `12 * x + base` is a multi-pass instruction whose result
+    // an LDS instruction issued right behind it has been seen to read too early in lanes 48-63 - a wrong FIRST read of a
+    // freshly computed address, different from run to run.  No v_mad_u64_u32 / v_mul_hi feeds an LDS address in this kernel.)
+    lds_group_bwd<ENV>(gz_base + (static_cast<unsigned>(ir[g2]) << 2), gv_base + __umul24(ir[g2], 12u), p4_base + 16u * le[g2],
+                       ed_base + 4u * le[g2], gz_base + (static_cast<unsigned>(ir[g2 + 1]) << 2),
+                       gv_base + __umul24(ir[g2 + 1], 12u), p4_base + 16u * le[g2 + 1], ed_base + 4u * le[g2 + 1], rd[0], rd[1]);
+    float gz[2], gdv[2][3], ed[2];
+    float4 re[2];
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      gz[u] = rd[u].one;
+#pragma unroll
+      for (int k = 0; k < 3; ++k) gdv[u][k] = rd[u].b[k];
+      re[u] = make_float4(rd[u].e[0], rd[u].e[1], rd[u].e[2], rd[u].e[3]);
+      ed[u] = rd[u].a[0];
+    }
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      const int su = g2 + u;
+      const float rk[3] = {re[u].x, re[u].y, re[u].z};
+      float wf[3], wd[3];
+#pragma unroll
+      for (int p = 0; p < 3; ++p) {
+        const float wx = acc[p][2 * su], fd = acc[p][2 * su + 1];   // x W + b (bias = k slot B) ; x' W
+        wf[p] = ENV ? wx * re[u].w : wx;
+        wd[p] = ENV ? fd * re[u].w + wx * ed[u] : fd;
+      }
+      float gsw[3];
+      gsw[0] = gz[u];
+      gsw[1] = gdv[u][0] * vj[0] + gdv[u][1] * vj[1] + gdv[u][2] * vj[2];
+      gsw[2] = gdv[u][0] * rk[0] + gdv[u][1] * rk[1] + gdv[u][2] * rk[2];
+      float gd = 0.0f;
+#pragma unroll
+      for (int p = 0; p < 3; ++p) {
+        gs[p] += gsw[p] * wf[p];
+        gd += gsw[p] * sj[p] * wd[p];
+      }
+      const float sw2 = sj[1] * wf[1], sw3 = sj[2] * wf[2];
+      red[4 * su] = gd;
+#pragma unroll
+      for (int k = 0; k < 3; ++k) {
+        gv[k] += gdv[u][k] * sw2;
+        red[4 * su + 1 + k] = gdv[u][k] * sw3;
+      }
+    }
+  }
+#pragma unroll
+  for (int i = 8 * G; i < 4 * NS; ++i) red[i] = 0.0f;
+  // lane c keeps component k_red of slot u_red; lanes whose low bits are not part of the slot index hold copies
+  const float tot = transpose_sum<4 * NS>(red, c);
+  const int k_red = ((c >> 4) & 1) + 2 * ((c >> 3) & 1);
+  int u_red = (c >> 2) & 1;
+  bool mine = true;
+  if constexpr (NS >= 4) u_red += 2 * ((c >> 1) & 1); else mine = (c & 2) == 0;
+  if constexpr (NS >= 8) u_red += 4 * (c & 1); else mine = mine && (c & 1) == 0;
+  if (mine && 2 * u_red + hh < nh) reinterpret_cast<float*>(part + first_edge + 2 * u_red + hh)[k_red] = tot;
+}
+
+template <int BT, bool ENV>
+__global__ __launch_bounds__(256, 2) void painn_message_bwd_tile_kernel(PainnBwdTileArgs a) {
+  extern __shared__ __align__(16) float lds[];
+  const int lane = threadIdx.x & 63;
+  const int fq = __builtin_amdgcn_readfirstlane(static_cast<int>(threadIdx.x >> 6));
+  const int hh = lane >> 5, c = lane & 31;
+  const int B = BT > 0 ? BT : a.B;
+  const int NG = BT == 20 ? 3 : painn_kgroups(B);
+  const int f0 = 32 * fq + c;
+  // A row c: slot, lane half and kind (0: basis row with the bias slot, 1: its derivative) of the edge it carries
+  const int uA = ((c & 3) >> 1) + 2 * (c >> 3), hA = (c >> 2) & 1, kind = c & 1;
+  float* const Gz = lds;                                                       // [rows][F]
+  float* const Gv = Gz + painn_pad(a.max_rows * F, 256);                       // [rows][3][F]
+  float* const Sj = Gv + painn_pad(a.max_rows * 3 * F, 256);                   // [senders][3F]    saved s of the tile's senders
+  float* const Vj = Sj + painn_pad(a.max_senders * 3 * F, 256);                // [senders][3][F]  block-input v
+  bf16x8* const Pc = reinterpret_cast<bf16x8*>(Vj + painn_pad(a.max_senders * 3 * F, 256));   // [edges][2][NG][3] + 3 zero
+  const int zunit = 2 * a.max_edges * NG * 3;
+  float4* const P4 = reinterpret_cast<float4*>(reinterpret_cast<float*>(Pc) + painn_pad((zunit + 3) * 4, 64));   // {r_ij, envelope}
+  float* const Ed = reinterpret_cast<float*>(P4) + painn_pad(a.max_edges * 4, 64);      // [edges] envelope' (ENV)
+  int* const Sd = reinterpret_cast<int*>(Ed + (ENV ? painn_pad(a.max_edges, 64) : 0));  // [edges] receiver row offset (floats of Gz)
+  int* const Rr = Sd + painn_pad(a.max_edges, 64);                             // [edges] stored edge id
+  float4* const Part = reinterpret_cast<float4*>(Rr + painn_pad(a.max_edges, 64));      // [4][edges] per-wave {g_d, g_rij}
+  if (threadIdx.x < 12) reinterpret_cast<float*>(Pc + zunit)[threadIdx.x] = 0.0f;
+  bf16x8 wb[3][2][3];
+  {
+    const bf16x8* img = reinterpret_cast<const bf16x8*>(a.wimg) + static_cast<size_t>(fq) * (3 * 2 * 3 * 64) + lane;
+#pragma unroll
+    for (int p = 0; p < 3; ++p)
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+        for (int pc = 0; pc < 3; ++pc) wb[p][ks][pc] = img[((p * 2 + ks) * 3 + pc) * 64];
+  }
+  const int N = static_cast<int>(a.N), M = static_cast<int>(a.M);
+  const int first = static_cast<int>(mp_xcd_block(blockIdx.x, gridDim.x));
+  for (int tile = first; tile < a.ntiles; tile += static_cast<int>(gridDim.x)) {
+    const int4 d0 = *reinterpret_cast<const int4*>(a.tiles + static_cast<int64_t>(tile) * 8);
+    const int2 d1 = *reinterpret_cast<const int2*>(a.tiles + static_cast<int64_t>(tile) * 8 + 4);
+    int j_lo = __builtin_amdgcn_readfirstlane(d0.x), j_hi = __builtin_amdgcn_readfirstlane(d0.y);
+    int s_lo = __builtin_amdgcn_readfirstlane(d0.z), s_hi = __builtin_amdgcn_readfirstlane(d0.w);
+    int e_lo = __builtin_amdgcn_readfirstlane(d1.x), e_hi = __builtin_amdgcn_readfirstlane(d1.y);
+    // a malformed table must not fault: everything is clamped into the arrays and into the LDS regions
+    j_lo = j_lo < 0 ? 0 : (j_lo > N ? N : j_lo);
+    j_hi = j_hi < j_lo ? j_lo : (j_hi > N ? N : j_hi);
+    if (j_hi - j_lo > 62) j_hi = j_lo + 62;
+    if (j_hi - j_lo > a.max_senders) j_hi = j_lo + a.max_senders;
+    s_lo = s_lo < 0 ? 0 : (s_lo > N - 1 ? N - 1 : s_lo);
+    s_hi = s_hi <= s_lo ? s_lo + 1 : (s_hi > N ? N : s_hi);
+    if (s_hi - s_lo > a.max_rows) s_hi = s_lo + a.max_rows;
+    e_lo = e_lo < 0 ? 0 : (e_lo > M ? M : e_lo);
+    e_hi = e_hi < e_lo ? e_lo : (e_hi > M ? M : e_hi);
+    if (e_hi - e_lo > a.max_edges) e_hi = e_lo + a.max_edges;
+    const int rows = s_hi - s_lo, ne = e_hi - e_lo, nj = j_hi - j_lo;
+    if (tile != first) __syncthreads();   // the previous tile's readers are done
+    // ---- the senders' own rows of s and v (contiguous), then the upstream gradients of the graph's nodes: 1-KB chunks
+    //      dealt to the four waves
+    if (nj > 0) {
+      const int nfl = nj * 3 * F;
+      const float* srcS = a.s + static_cast<int64_t>(j_lo) * 3 * F;
+      const float* srcV = a.v + static_cast<int64_t>(j_lo) * 3 * F;
+      for (int ch = fq; ch * 256 < nfl; ch += 4) {
+        int off = ch * 256 + lane * 4;
+        off = off < nfl - 4 ? off : nfl - 4;
+        __builtin_amdgcn_global_load_lds(srcS + off, (__attribute__((address_space(3))) void*)(Sj + ch * 256), 16, 0, 0);
+        __builtin_amdgcn_global_load_lds(srcV + off, (__attribute__((address_space(3))) void*)(Vj + ch * 256), 16, 0, 0);
+      }
+    }
+    {
+      const int nz = rows * F, nv = rows * 3 * F;
+      const float* srcZ = a.g_ds + static_cast<int64_t>(s_lo) * F;
+      const float* srcV = a.g_dv + static_cast<int64_t>(s_lo) * 3 * F;
+      for (int ch = fq; ch * 256 < nv; ch += 4) {
+        int off = ch * 256 + lane * 4;
+        int offv = off < nv - 4 ? off : nv - 4;
+        __builtin_amdgcn_global_load_lds(srcV + offv, (__attribute__((address_space(3))) void*)(Gv + ch * 256), 16, 0, 0);
+        if (ch * 256 < nz) {
+          int offz = off < nz - 4 ? off : nz - 4;
+          __builtin_amdgcn_global_load_lds(srcZ + offz, (__attribute__((address_space(3))) void*)(Gz + ch * 256), 16, 0, 0);
+        }
+      }
+    }
+    // ---- A operands of the tile's edges, split ONCE for the four waves: task = (edge, kind, k group of 8) gathers its eight
+    //      values through perm1 and leaves the three bf16 pieces as 16-B units [edge][kind][group][piece]; two tasks per
+    //      thread and pass, their loads issued together (index arithmetic by shifts and 24-bit multiplies only)
+    {
+      const int ntask = 2 * ne * 4;                           // task = 4 row + k group (group 3 idles when NG = 3)
+      for (int t0 = threadIdx.x; t0 < ntask; t0 += 512) {
+        float x[2][8];
+        int tt[2];
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+          int t = t0 + 256 * h;
+          t = t < ntask ? t : ntask - 1;                      // a repeated task rewrites the same values
+          const int row = t >> 2, e = row >> 1, kd = row & 1;
+          int g = t & 3;
+          g = g < NG ? g : NG - 1;                            // the idle group repeats the last one's values
+          tt[h] = __umul24(row, 3 * NG) + 3 * g;              // first 16-B unit of the task
+          int r = a.perm1 ? a.perm1[e_lo + e] : e_lo + e;
+          r = r < 0 ? 0 : (r >= M ? M - 1 : r);
+          const float* tab = (kd ? a.rbfd : a.rbf) + static_cast<int64_t>(r) * B;
+          if constexpr (BT == 20) {   // 80-B rows: 16-B pieces, unconditional from clamped offsets, masked afterwards
+            const float4 q0 = *reinterpret_cast<const float4*>(tab + (g < 2 ? 8 * g : 16));
+            const float4 q1 = *reinterpret_cast<const float4*>(tab + (g < 2 ? 8 * g + 4 : 16));
+            const float m = g < 2 ? 1.0f : 0.0f;
+            x[h][0] = q0.x; x[h][1] = q0.y; x[h][2] = q0.z; x[h][3] = q0.w;
+            x[h][4] = g < 2 ? q1.x : (kd ? 0.0f : 1.0f);       // k = 20: the bias slot
+            x[h][5] = q1.y * m; x[h][6] = q1.z * m; x[h][7] = q1.w * m;
+          } else {
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+              const int k = 8 * g + i;
+              const float y = tab[k < B ? k : B - 1];
+              x[h][i] = k < B ? y : ((k == B && !kd) ? 1.0f : 0.0f);
+            }
+          }
+        }
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+          bf16x8 pc[3];
+#pragma unroll
+          for (int i = 0; i < 8; ++i) split3_into(x[h][i], pc[0], pc[1], pc[2], i);
+#pragma unroll
+          for (int q = 0; q < 3; ++q) Pc[tt[h] + q] = pc[q];
+        }
+      }
+    }
+    // ---- per edge: stored id, receiver row inside the tile, unit vector + envelope as one 16-B entry
+    for (int i = threadIdx.x; i < ne; i += 256) {
+      int r = a.perm1 ? a.perm1[e_lo + i] : e_lo + i;
+      r = r < 0 ? 0 : (r >= M ? M - 1 : r);
+      int ir = a.recv[r] - s_lo;
+      ir = ir < 0 ? 0 : (ir >= rows ? rows - 1 : ir);
+      Rr[i] = r;
+      Sd[i] = ir * F;
+      P4[i] = make_float4(a.rij[static_cast<int64_t>(r) * 3], a.rij[static_cast<int64_t>(r) * 3 + 1],
+                          a.rij[static_cast<int64_t>(r) * 3 + 2], ENV ? a.env[r] : 1.0f);
+      if (ENV) Ed[i] = a.envd ? a.envd[r] : 0.0f;
+    }
+    // edge ranges of the tile's senders: lane i holds ptr1[j_lo + i]
+    int ptrv = a.ptr1[(j_lo + lane) <= j_hi ? j_lo + lane : j_hi];
+    ptrv = ptrv < e_lo ? e_lo : (ptrv > e_hi ? e_hi : ptrv);
+    __builtin_amdgcn_s_waitcnt(0);      // DMA + stores issued by this wave have landed
+    __syncthreads();
+    float4* const part = Part + fq * a.max_edges;
+    for (int jj = 0; jj < nj; ++jj) {
+      const int j = j_lo + jj;
+      const int lo = __builtin_amdgcn_readlane(ptrv, jj) - e_lo;
+      const int cnt = __builtin_amdgcn_readlane(ptrv, jj + 1) - e_lo - lo;
+      float sj[3], vj[3], gs[3] = {0.0f, 0.0f, 0.0f}, gv[3] = {0.0f, 0.0f, 0.0f};
+#pragma unroll
+      for (int p = 0; p < 3; ++p) {
+        sj[p] = Sj[jj * 3 * F + p * F + f0];
+        vj[p] = Vj[jj * 3 * F + p * F + f0];
+      }
+      lds_wait_all();                                         // six 4-B reads, complete before the 16-B operand reads
+      for (int cb = 0; cb < cnt; cb += 16) {
+        const int nh = cnt - cb < 16 ? cnt - cb : 16;         // edges of this step
+        // A operand: row c = kind `kind` of the edge in slot uA of lane half hA; rows past the step and the k groups
+        // beyond the bias slot read the zero units
+        const bool rv = 2 * uA + hA < nh;
+        const int rowu = __umul24(2 * (lo + cb + 2 * uA + hA) + kind, 3 * NG);
+        const int u0 = rv ? rowu + 3 * hh : zunit;
+        const int u1 = (rv && 2 + hh < NG) ? rowu + 6 + 3 * hh : zunit;
+        bf16x8 qa[2][3];
+#pragma unroll
+        for (int q = 0; q < 3; ++q) {
+          qa[0][q] = Pc[u0 + q];
+          qa[1][q] = Pc[u1 + q];
+        }
+        lds_wait_all();                                       // six 16-B reads: uniform
+        // the six leading products of the three-piece split, smallest first, for both k blocks and the three parts in turn
+        // (36 MFMAs of 32 cycles: at two waves per SIMD this phase runs at the matrix pipe's rate)
+        floatx16 acc[3];
+#pragma unroll
+        for (int p = 0; p < 3; ++p)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) acc[p][r] = 0.0f;
+        {
+          constexpr int PA[6] = {2, 0, 1, 1, 0, 0}, PB[6] = {0, 2, 1, 0, 1, 0};
+#pragma unroll
+          for (int pr = 0; pr < 6; ++pr)
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+              for (int p = 0; p < 3; ++p)
+                acc[p] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qa[ks][PA[pr]], wb[p][ks][PB[pr]], acc[p], 0, 0, 0);
+        }
+        mfma_drained(acc);
+        // the lane's slots: edge 2 u + hh of the step, in groups of two; a code path per group count, so that no register
+        // state of a skipped group has to be merged
+        const int first_edge = lo + cb;
+        const int ng = (nh + 3) >> 2;
+        if (ng >= 4) painn_bwd_slots<4, ENV>(acc, Gz, Gv, P4, Ed, Sd, part, first_edge, nh, hh, c, f0, sj, vj, gs, gv);
+        else if (ng == 3) painn_bwd_slots<3, ENV>(acc, Gz, Gv, P4, Ed, Sd, part, first_edge, nh, hh, c, f0, sj, vj, gs, gv);
+        else if (ng == 2) painn_bwd_slots<2, ENV>(acc, Gz, Gv, P4, Ed, Sd, part, first_edge, nh, hh, c, f0, sj, vj, gs, gv);
+        else painn_bwd_slots<1, ENV>(acc, Gz, Gv, P4, Ed, Sd, part, first_edge, nh, hh, c, f0, sj, vj, gs, gv);
+      }
+      // even + odd edges of the sender
+#pragma unroll
+      for (int p = 0; p < 3; ++p) {
+        gs[p] = sum_halves(gs[p]);
+        gv[p] = sum_halves(gv[p]);
+      }
+      if (hh == 0) {
+#pragma unroll
+        for (int p = 0; p < 3; ++p) a.g_s[static_cast<int64_t>(j) * 3 * F + p * F + f0] = gs[p];
+        if (a.g_v) {     // the sender's own upstream row is among the staged ones
+          int jr = j - s_lo;
+          jr = jr < 0 ? 0 : (jr >= rows ? rows - 1 : jr);
+          float own[3];
+#pragma unroll
+          for (int k = 0; k < 3; ++k) own[k] = Gv[jr * 3 * F + k * F + f0];
+          lds_wait_all();
+#pragma unroll
+          for (int k = 0; k < 3; ++k) a.g_v[(static_cast<int64_t>(j) * 3 + k) * F + f0] = own[k] + gv[k];
+        }
+      }
+    }
+    __syncthreads();     // every wave's per-edge partials are parked
+    for (int e = threadIdx.x; e < ne; e += 256) {   // one thread per edge: the four waves' slabs in fixed order
+      const int r = Rr[e];
+      lds_wait_all();                                         // the 4-B read is complete before the 16-B ones are issued
+      const float4 p0 = Part[e], p1 = Part[a.max_edges + e], p2 = Part[2 * a.max_edges + e], p3 = Part[3 * a.max_edges + e];
+      lds_wait_all();
+      float t[4] = {((p0.x + p1.x) + p2.x) + p3.x, ((p0.y + p1.y) + p2.y) + p3.y, ((p0.z + p1.z) + p2.z) + p3.z,
+                    ((p0.w + p1.w) + p2.w) + p3.w};
+      float* dr = a.g_rij + static_cast<int64_t>(r) * 3;
+      if (a.accumulate) {
+        const float o0 = a.g_d[r], o1 = dr[0], o2 = dr[1], o3 = dr[2];
+        t[0] += o0; t[1] += o1; t[2] += o2; t[3] += o3;
+      }
+      a.g_d[r] = t[0];
+      dr[0] = t[1]; dr[1] = t[2]; dr[2] = t[3];
     }
   }
 }
@@ -1306,6 +1798,60 @@ int mp_painn_message_tiles_f32(const float* s, const float* v, int64_t N, const 
   else lr = env ? launch(painn_message_tile_kernel<0, true>) : launch(painn_message_tile_kernel<0, false>);
   if (lr != MP_OK) return lr;
   return mp::check_launch("mp_painn_message_tiles_f32");
+}
+
+int mp_painn_message_bwd_tiles_lds_bytes(int max_rows, int max_senders, int max_edges, int B, int with_env, size_t* out) {
+  MP_REQUIRE(max_rows >= 1 && max_senders >= 1 && max_senders <= 62 && max_edges >= 0 && B >= 1 && B <= 31 && out,
+             "mp_painn_message_bwd_tiles_lds_bytes: bad arguments");
+  MP_REQUIRE(max_rows <= 4096 && max_edges <= (1 << 20), "mp_painn_message_bwd_tiles_lds_bytes: tile far beyond LDS");
+  *out = static_cast<size_t>(painn_bwd_tile_lds_floats(max_rows, max_senders, max_edges, B, with_env != 0)) * 4;
+  return MP_OK;
+}
+
+int mp_painn_message_bwd_tiles_f32(const float* s, const float* v, int64_t N, const float* rbf, const float* rbfd, int B,
+                                   const float* env, const float* envd, const float* rij, const void* wimage,
+                                   const int32_t* ptr1, const int32_t* perm1, const int32_t* recv, int64_t M,
+                                   const int32_t* tiles, int ntiles, int max_rows, int max_senders, int max_edges,
+                                   const float* g_ds, const float* g_dv, float* g_s, float* g_v, float* g_d, float* g_rij,
+                                   int accumulate, mpStream_t stream) {
+  MP_REQUIRE(N >= 0 && M >= 0 && B >= 1 && B <= 31 && ntiles >= 0,
+             "mp_painn_message_bwd_tiles_f32: bad sizes (B must be 1..31)");
+  if (N == 0 || ntiles == 0) return MP_OK;
+  MP_REQUIRE(s && v && wimage && ptr1 && tiles && g_ds && g_dv && g_s && (M == 0 || (rbf && rbfd && rij && recv && g_d && g_rij)),
+             "mp_painn_message_bwd_tiles_f32: null pointer");
+  MP_REQUIRE(M < (int64_t{1} << 31) && N < (int64_t{1} << 31), "mp_painn_message_bwd_tiles_f32: sizes must fit int32");
+  MP_REQUIRE(g_v != g_dv, "mp_painn_message_bwd_tiles_f32: g_v must not alias g_dv (other tiles still stage g_dv)");
+  size_t lds = 0;
+  const int rc = mp_painn_message_bwd_tiles_lds_bytes(max_rows, max_senders, max_edges, B, env != nullptr, &lds);
+  if (rc != MP_OK) return rc;
+  MP_REQUIRE(lds <= 160 * 1024,
+             "mp_painn_message_bwd_tiles_f32: a tile of %d node rows, %d senders and %d edges needs %zu B of LDS (> 160 KB)",
+             max_rows, max_senders, max_edges, lds);
+  PainnBwdTileArgs a{s,    v,    rbf,  rbfd, env, envd, rij,   wimage,     tiles, ptr1, perm1, recv, g_ds,      g_dv,
+                     g_s,  g_v,  g_d,  g_rij, accumulate, N,   M,   B,     ntiles, max_rows, max_senders, max_edges};
+  hipStream_t st = mp::as_stream(stream);
+  const unsigned blocks = static_cast<unsigned>(ntiles < 2048 ? ntiles : 2048);
+  auto launch = [&](auto kernel) -> int {
+    static std::mutex mu;
+    static unsigned long long done = 0;       // one static pair per instantiation of this lambda's call operator
+    int dev = 0;
+    MP_HIP(hipGetDevice(&dev));
+    {
+      std::lock_guard<std::mutex> lock(mu);
+      if (dev >= 64 || !((done >> dev) & 1ull)) {
+        MP_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                   160 * 1024));
+        if (dev < 64) done |= 1ull << dev;
+      }
+    }
+    kernel<<<blocks, 256, lds, st>>>(a);
+    return MP_OK;
+  };
+  int lr;
+  if (B == 20) lr = env ? launch(painn_message_bwd_tile_kernel<20, true>) : launch(painn_message_bwd_tile_kernel<20, false>);
+  else lr = env ? launch(painn_message_bwd_tile_kernel<0, true>) : launch(painn_message_bwd_tile_kernel<0, false>);
+  if (lr != MP_OK) return lr;
+  return mp::check_launch("mp_painn_message_bwd_tiles_f32");
 }
 
 int mp_painn_message_bwd_f32(const float* s, const float* v, int64_t N, const float* rbf, const float* rbfd, int B,

@@ -102,20 +102,23 @@ def make_images(p, depth, n_out, out=None):
     return images
 
 
-def message_tile_table(node_splits, ptr, basis, per=None, lds_limit=160 * 1024):
+def message_tile_table(node_splits, ptr, basis, per=None, lds_limit=160 * 1024, reverse=False):
     """Tile table of ``mp_painn_message_tiles_f32`` (csrc/mp_painn_fused.hip) from host arrays: ``(T, 8)`` int32 rows
     ``{r_lo, r_hi, s_lo, s_hi, e_lo, e_hi, 0, 0}`` - a few consecutive nodes ``[r_lo, r_hi)`` of ONE graph, the graph's node
     range ``[s_lo, s_hi)`` (whose s / v rows the workgroup stages: a tile's senders lie in its own graph) and the tile's
     edge range ``[ptr[r_lo], ptr[r_hi])`` in the receiver CSR.  ``per`` nodes per tile (default: enough tiles for two
     workgroups per CU, at least 2, at most 62).  Returns ``{"table", "count", "max_rows", "max_edges"}`` or None when a
-    graph's rows and a tile's edge data do not fit ``lds_limit`` bytes of LDS."""
+    graph's rows and a tile's edge data do not fit ``lds_limit`` bytes of LDS.  ``reverse``: the table of
+    ``mp_painn_message_bwd_tiles_f32`` - the same rows over SENDERS and the sender CSR ``ptr1`` (LDS need of that kernel)."""
     ns = np.asarray(node_splits, dtype=np.int64)
     ptr = np.asarray(ptr, dtype=np.int64)
     n = int(ns[-1]) if len(ns) else 0
     if n == 0 or basis > 31:
         return None
     sizes = ns[1:] - ns[:-1]
-    per = int(per) if per else max(2, 2 * int(-(-n // 1024)))
+    # forward: two receivers per wave step, tiles for two workgroups per CU; reverse: every sender is a serial chain of
+    # its wave (~3 us), so as few senders per tile as one round of 512 resident workgroups allows
+    per = int(per) if per else (max(2, int(-(-n // 448))) if reverse else max(2, 2 * int(-(-n // 1024))))
     per = max(1, min(per, 62))
     count = -(-sizes // per)                                      # tiles per graph
     total = int(count.sum())
@@ -131,10 +134,14 @@ def message_tile_table(node_splits, ptr, basis, per=None, lds_limit=160 * 1024):
     table[:, 4], table[:, 5] = ptr[r_lo], ptr[r_hi]
     max_rows, max_edges = int(sizes.max()), int((table[:, 5] - table[:, 4]).max())
     lds = ctypes.c_size_t(0)
-    _ffi.call("mp_painn_message_tiles_lds_bytes", max_rows, max_edges, int(basis), 1, ctypes.byref(lds))
+    max_own = int((r_hi - r_lo).max())
+    if reverse:
+        _ffi.call("mp_painn_message_bwd_tiles_lds_bytes", max_rows, max_own, max_edges, int(basis), 1, ctypes.byref(lds))
+    else:
+        _ffi.call("mp_painn_message_tiles_lds_bytes", max_rows, max_edges, int(basis), 1, ctypes.byref(lds))
     if lds.value > lds_limit:
         return None
-    return {"table": table, "count": total, "max_rows": max_rows, "max_edges": max_edges}
+    return {"table": table, "count": total, "max_rows": max_rows, "max_edges": max_edges, "max_own": max_own}
 
 
 class FusedPainn:
@@ -177,7 +184,11 @@ class FusedPainn:
             raise IndexError("edge index out of range for its graph")
         self.ptr0, self.perm0, _ = plan.csr(0)
         self.ptr1, self.perm1, _ = plan.csr(1) if self.grad else (None, None, None)
-        self.tiles0 = self._tile_table(node, self.ptr0, self.perm0, self.B + 4 + (1 if self.cos_cutoff > 0 else 0))
+        self.tiles0 = self._tile_table(node, self.ptr0, self.perm0)
+        # the reverse kernel gathers its tile's edge data through perm1: any edge order
+        self.tiles1 = self._tile_table(node, self.ptr1, None, reverse=True) if self.grad else None
+        if os.environ.get("MPENGINE_PAINN_BWD_TILES") == "0":
+            self.tiles1 = None
         mm = max(m, 1)
         self.recv = torch.empty(mm, dtype=torch.int32, device=dev)
         self.send = torch.empty(mm, dtype=torch.int32, device=dev)
@@ -216,7 +227,7 @@ class FusedPainn:
         self.graphs = {}
         self.rings = {}
 
-    def _tile_table(self, node, ptr, perm, floats_per_edge):
+    def _tile_table(self, node, ptr, perm, reverse=False):
         """Tiles of the LDS-staged message kernel for this batch (``message_tile_table``), on the device; None when the
         kernel does not apply: permuted (unsorted) edge lists, basis sizes without a free bias slot, graphs whose node
         rows do not fit LDS, ``MPENGINE_PAINN_TILES=0``."""
@@ -225,7 +236,7 @@ class FusedPainn:
             return None
         # the CSR is read back once per bound batch: a few KB, next to the flag word bind reads anyway
         tl = message_tile_table(node.row_splits_host(), ptr.cpu().numpy(), self.B,
-                                per=int(os.environ.get("MPENGINE_PAINN_TILE_R", "0")) or None)
+                                per=int(os.environ.get("MPENGINE_PAINN_TILE_R", "0")) or None, reverse=reverse)
         if tl is None:
             return None
         tl["table"] = torch.from_numpy(tl["table"]).to(node.values.device)
@@ -319,6 +330,7 @@ class FusedPainn:
         if not self.fast_readout:
             _ffi.call("mp_repeat_rows_f32", _ffi.ptr(t), _ffi.ptr(node.row_splits), self.G, 128, n, _ffi.ptr(self.gz),
                       _ffi.stream())
+        tiles = self.tiles1 is not None and all(("conv%d/w/F" % i) in w for i in range(self.depth))
         # the readout sees z only: no gradient reaches the last block's v'' (null pointer = zeros, no fill launch)
         for i in range(self.depth - 1, -1, -1):
             c, u = "conv%d/" % i, "update%d/" % i
@@ -331,16 +343,25 @@ class FusedPainn:
                       0.0, _ffi.ptr(b["h2"]), _ffi.ptr(w[u + "dense1/TP"]), _ffi.ptr(self.g_zp), _ffi.ptr(self.g_uv),
                       _ffi.stream())
             self._chain(self.g_uv, 3 * n, 256, w["uvT%d/P" % i], None, 128, self.g_vp, addend=gv_in)
-            _ffi.call("mp_painn_message_bwd_f32", _ffi.ptr(b["s"]), _ffi.ptr(v_in), n, _ffi.ptr(self.rbf),
-                      _ffi.ptr(self.rbfd), self.B, _ffi.ptr(self.env), _ffi.ptr(self.envd), _ffi.ptr(self.rij),
-                      _ffi.ptr(p[c + "w/kernel"]), _ffi.ptr(p.get(c + "w/bias")), _ffi.ptr(self.ptr1),
-                      _ffi.ptr(self.perm1), _ffi.ptr(self.recv), m, _ffi.ptr(self.g_zp), _ffi.ptr(self.g_vp),
-                      _ffi.ptr(self.g_s), _ffi.ptr(self.gv) if i > 0 else None, _ffi.ptr(self.g_d), _ffi.ptr(self.g_rij),
-                      0 if i == self.depth - 1 else 1, _ffi.stream())
+            if tiles:     # sender tiles in LDS, filter and its derivative on the matrix pipe; one slice of g_d / g_rij
+                tl = self.tiles1
+                _ffi.call("mp_painn_message_bwd_tiles_f32", _ffi.ptr(b["s"]), _ffi.ptr(v_in), n, _ffi.ptr(self.rbf),
+                          _ffi.ptr(self.rbfd), self.B, _ffi.ptr(self.env), _ffi.ptr(self.envd), _ffi.ptr(self.rij),
+                          _ffi.ptr(w[c + "w/F"]), _ffi.ptr(self.ptr1), _ffi.ptr(self.perm1), _ffi.ptr(self.recv), m,
+                          _ffi.ptr(tl["table"]), tl["count"], tl["max_rows"], tl["max_own"], tl["max_edges"], _ffi.ptr(self.g_zp),
+                          _ffi.ptr(self.g_vp), _ffi.ptr(self.g_s), _ffi.ptr(self.gv) if i > 0 else None,
+                          _ffi.ptr(self.g_d), _ffi.ptr(self.g_rij), 0 if i == self.depth - 1 else 1, _ffi.stream())
+            else:
+                _ffi.call("mp_painn_message_bwd_f32", _ffi.ptr(b["s"]), _ffi.ptr(v_in), n, _ffi.ptr(self.rbf),
+                          _ffi.ptr(self.rbfd), self.B, _ffi.ptr(self.env), _ffi.ptr(self.envd), _ffi.ptr(self.rij),
+                          _ffi.ptr(p[c + "w/kernel"]), _ffi.ptr(p.get(c + "w/bias")), _ffi.ptr(self.ptr1),
+                          _ffi.ptr(self.perm1), _ffi.ptr(self.recv), m, _ffi.ptr(self.g_zp), _ffi.ptr(self.g_vp),
+                          _ffi.ptr(self.g_s), _ffi.ptr(self.gv) if i > 0 else None, _ffi.ptr(self.g_d),
+                          _ffi.ptr(self.g_rij), 0 if i == self.depth - 1 else 1, _ffi.stream())
             if i > 0:   # block 0's inputs (embedding, constant v) do not depend on the coordinates
                 self._chain(self.g_s, n, 384, w[c + "phi/TP"], None, 128, self.gz, act=self.act_conv, grad_pre=b["h1"],
                             w2=w[c + "dense1/TP"], u2=128, addend=self.g_zp)
-        _ffi.call("mp_edge_geometry_bwd_f32", _ffi.ptr(self.g_d), _ffi.ptr(self.g_rij), 2, _ffi.ptr(self.rij),
+        _ffi.call("mp_edge_geometry_bwd_f32", _ffi.ptr(self.g_d), _ffi.ptr(self.g_rij), 1 if tiles else 2, _ffi.ptr(self.rij),
                   _ffi.ptr(self.dist), _ffi.ptr(self.ptr0), _ffi.ptr(self.perm0), _ffi.ptr(self.ptr1),
                   _ffi.ptr(self.perm1), n, m, -1.0, _ffi.ptr(self.force), _ffi.stream())
 

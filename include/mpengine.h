@@ -339,6 +339,21 @@ int mp_painn_message_bwd_f32(const float* s, const float* v, int64_t N, const fl
                              const int32_t* ptr1, const int32_t* perm1, const int32_t* recv, int64_t M, const float* g_ds,
                              const float* g_dv, float* g_s, float* g_v, float* g_d, float* g_rij, int accumulate,
                              mpStream_t stream);
+/* The same reverse step on SENDER tiles staged in LDS with the filter AND its distance derivative on the matrix pipe (A rows
+ * [rbf_e | 1] and [rbf'_e | 0] against the forward kernel's packed image `wimage`): any edge order (the tile's basis rows are
+ * gathered through perm1), batched graphs.  tiles (T,8) int32 = {j_lo, j_hi, s_lo, s_hi, e_lo, e_hi, 0, 0}: senders
+ * [j_lo, j_hi) (at most max_senders <= 62: their s / v rows are staged too) of ONE graph whose nodes are [s_lo, s_hi)
+ * (<= max_rows: the g_ds / g_dv rows staged) and whose
+ * edges are the sender-order positions [e_lo, e_hi) = [ptr1[j_lo], ptr1[j_hi]) (<= max_edges); every sender in exactly one
+ * tile.  g_d (M), g_rij (M,3): ONE slice (mp_edge_geometry_bwd_f32 with slices = 1), summed over the feature axis in a
+ * fixed order inside the kernel.  LDS per workgroup: mp_painn_message_bwd_tiles_lds_bytes (<= 160 KB, else MP_EINVAL). */
+int mp_painn_message_bwd_tiles_lds_bytes(int max_rows, int max_senders, int max_edges, int B, int with_env, size_t* out);
+int mp_painn_message_bwd_tiles_f32(const float* s, const float* v, int64_t N, const float* rbf, const float* rbfd, int B,
+                                   const float* env, const float* envd, const float* rij, const void* wimage,
+                                   const int32_t* ptr1, const int32_t* perm1, const int32_t* recv, int64_t M,
+                                   const int32_t* tiles, int ntiles, int max_rows, int max_senders, int max_edges,
+                                   const float* g_ds, const float* g_dv, float* g_s, float* g_v, float* g_d, float* g_rij,
+                                   int accumulate, mpStream_t stream);
 /* PAiNNUpdate.call (painn_conv.py:201-214) around its GEMMs; uv (3N,2F) = v [Wu | Wv] (rows (n,k)):
  * pre:  c (N,2F) = [z | EuclideanNorm_k(v_v)], prod (N,F) = ScalarProduct_k(v_u, v_v);
  * post: z2 = z + prod a_sv + a_ss, v2 = v + a_vv (x) v_u  with a (N,3F) = [a_vv | a_sv | a_ss] (+ PAiNN.py:131-132);

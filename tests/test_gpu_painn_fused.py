@@ -227,3 +227,58 @@ def test_painn_launch_group_energy_and_forces():
     f32, f64 = _reference_forces(p, batches[1])
     assert_forces_close(moved[1][1].cpu().numpy(), f32, f64, batches[1]["node_splits"], what="PaiNN group forces after a move")
     energy.fused.check_flags()
+
+
+@pytest.mark.parametrize("cutoff,shuffle", [(None, False), (5.0, False), (None, True)])
+def test_reverse_message_tiles_against_gather_route_and_replays(monkeypatch, cutoff, shuffle):
+    """The reverse message step on sender tiles (``mp_painn_message_bwd_tiles_f32``: upstream gradients staged by LDS-DMA,
+    basis rows gathered through perm1 and split once per tile, filter and its distance derivative on the matrix pipe) is
+    what every bound batch runs for forces - receiver-sorted or not; ``MPENGINE_PAINN_BWD_TILES=0`` keeps the sender-parallel
+    VALU kernel.  Both routes against the analytic float64 forces and against each other on QM9-shaped molecules (3-29
+    atoms: tiles of one to three senders, steps of 1 to 16 edges, an atom without edges), with and without the cosine
+    cutoff envelope, with the edge list shuffled inside every graph; 150 replays bit-identical (the kernel's LDS reads sit
+    behind full waits and a drained MFMA burst: csrc/mp_painn_fused.hip, `mfma_drained`); a tile that cannot fit LDS is
+    refused with ValueError, never launched."""
+    from gcnn_keras_amd import _ffi
+    b = synth.qm9_like_batch(num_graphs=24, seed=92, max_distance=5.0, max_neighbours=10000)
+    b["node_coordinates"][int(b["node_splits"][5])] += 50.0          # an atom out of everyone's reach: no edges at all
+    b = dict(b, **{k: v for k, v in _edges_by_rule(b).items()})
+    if shuffle:
+        rng = np.random.default_rng(4)
+        idx = b["edge_indices"].copy()
+        for g in range(len(b["edge_splits"]) - 1):
+            lo, hi = int(b["edge_splits"][g]), int(b["edge_splits"][g + 1])
+            idx[lo:hi] = idx[lo:hi][rng.permutation(hi - lo)]
+        b = dict(b, edge_indices=idx)
+    p = synth.painn_params(seed=8, random_bias=True)
+    kw = {"conv_args": {"units": 128, "cutoff": cutoff, "conv_pool": "sum"}}
+    f32, f64 = _reference_forces(p, b, cutoff=cutoff)
+    energy = _model(p, **kw)
+    x = mol_inputs(b)
+    eng, force = energy.fused.energy_force(x)
+    slot = energy.fused.slot_of(x, grad=True)
+    assert slot.tiles1 is not None and slot.tiles1["max_own"] <= 3 and slot.tiles1["max_rows"] <= 29
+    assert (slot.perm0 is not None) == shuffle
+    first = force.clone()
+    # cap 2e-4: these random-geometry molecules include ill-conditioned ones on which the float32 autograd reference itself
+    # is 4e-5 of the molecule's scale from float64 - the bar stays twice that reference's own distance, per molecule
+    assert_forces_close(force.cpu().numpy(), f32, f64, b["node_splits"], what="PaiNN forces, sender tiles", cap=2e-4)
+    for _ in range(150):
+        e2, f2 = energy.fused.energy_force(x)
+        assert torch.equal(f2, first) and torch.equal(e2, eng)
+    monkeypatch.setenv("MPENGINE_PAINN_BWD_TILES", "0")
+    other = _model(p, **kw)
+    x2 = mol_inputs(b)
+    eng_v, force_v = other.fused.energy_force(x2)
+    assert other.fused.slot_of(x2, grad=True).tiles1 is None
+    assert_forces_close(force_v.cpu().numpy(), f32, f64, b["node_splits"], what="PaiNN forces, sender-parallel kernel", cap=2e-4)
+    assert_forces_close(force.cpu().numpy(), force_v.cpu().numpy(), f64, b["node_splits"], what="PaiNN forces, tiles vs VALU",
+                        cap=2e-4)
+    monkeypatch.delenv("MPENGINE_PAINN_BWD_TILES")
+    tl, blk = slot.tiles1, slot.blk[0]
+    with pytest.raises(ValueError):
+        _ffi.call("mp_painn_message_bwd_tiles_f32", _ffi.ptr(blk["s"]), _ffi.ptr(slot.v0), slot.N, _ffi.ptr(slot.rbf),
+                  _ffi.ptr(slot.rbfd), slot.B, _ffi.ptr(slot.env), _ffi.ptr(slot.envd), _ffi.ptr(slot.rij),
+                  _ffi.ptr(slot.w["conv0/w/F"]), _ffi.ptr(slot.ptr1), _ffi.ptr(slot.perm1), _ffi.ptr(slot.recv), slot.M,
+                  _ffi.ptr(tl["table"]), tl["count"], 60, 40, 400, _ffi.ptr(slot.g_zp), _ffi.ptr(slot.g_vp), _ffi.ptr(slot.g_s),
+                  None, _ffi.ptr(slot.g_d), _ffi.ptr(slot.g_rij), 0, _ffi.stream())
