@@ -118,7 +118,9 @@ def message_tile_table(node_splits, ptr, basis, per=None, lds_limit=160 * 1024, 
     sizes = ns[1:] - ns[:-1]
     # forward: two receivers per wave step, tiles for two workgroups per CU; reverse: every sender is a serial chain of
     # its wave (~3 us), so as few senders per tile as one round of 512 resident workgroups allows
-    per = int(per) if per else (max(2, int(-(-n // 448))) if reverse else max(2, 2 * int(-(-n // 1024))))
+    # (two or three: three senders with their graph's gradient rows are ~77 KB of LDS, two workgroups per CU; larger
+    # batches take more rounds of the same tiles)
+    per = int(per) if per else (min(3, max(2, int(-(-n // 448)))) if reverse else max(2, 2 * int(-(-n // 1024))))
     per = max(1, min(per, 62))
     count = -(-sizes // per)                                      # tiles per graph
     total = int(count.sum())

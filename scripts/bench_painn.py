@@ -113,6 +113,21 @@ def main():
                   _ffi.ptr(slot.g_zp), _ffi.ptr(slot.g_vp), _ffi.ptr(slot.g_s), _ffi.ptr(slot.gv), _ffi.ptr(slot.g_d),
                   _ffi.ptr(slot.g_rij), 0, _ffi.stream())
 
+    def msg_tiles():
+        tl = slot.tiles0
+        _ffi.call("mp_painn_message_tiles_f32", _ffi.ptr(blk["s"]), _ffi.ptr(v_in), n, _ffi.ptr(slot.rbf), slot.B, None,
+                  _ffi.ptr(slot.rij), _ffi.ptr(w["conv1/w/F"]), _ffi.ptr(slot.ptr0), _ffi.ptr(slot.send), m,
+                  _ffi.ptr(tl["table"]), tl["count"], tl["max_rows"], tl["max_edges"], _ffi.ptr(slot.zs[0]),
+                  _ffi.ptr(blk["zp"]), _ffi.ptr(blk["vp"]), _ffi.stream())
+
+    def msg_bwd_tiles():
+        tl = slot.tiles1
+        _ffi.call("mp_painn_message_bwd_tiles_f32", _ffi.ptr(blk["s"]), _ffi.ptr(v_in), n, _ffi.ptr(slot.rbf),
+                  _ffi.ptr(slot.rbfd), slot.B, None, None, _ffi.ptr(slot.rij), _ffi.ptr(w["conv1/w/F"]), _ffi.ptr(slot.ptr1),
+                  _ffi.ptr(slot.perm1), _ffi.ptr(slot.recv), m, _ffi.ptr(tl["table"]), tl["count"], tl["max_rows"],
+                  tl["max_own"], tl["max_edges"], _ffi.ptr(slot.g_zp), _ffi.ptr(slot.g_vp), _ffi.ptr(slot.g_s),
+                  _ffi.ptr(slot.gv), _ffi.ptr(slot.g_d), _ffi.ptr(slot.g_rij), 0, _ffi.stream())
+
     def gemm():
         slot._chain(blk["vp"], 3 * n, 128, w["uv1/P"], None, 256, blk["uv"])
 
@@ -122,15 +137,22 @@ def main():
 
     f = 128
     kernels = {}
-    for name, fn, flops, nbytes, bound in (
-            ("painn_message_kernel", msg, m * (6 * 20 * f + 12 * f), 4 * (3 * n * f * 2 + 4 * n * f * 2) + m * (4 * 20 + 24),
+    tiled = []
+    if slot.tiles0 is not None:      # the default kernels of a receiver-sorted batch: tiles in LDS, filter on the matrix pipe
+        tiled.append(("painn_message_tile_kernel (default)", msg_tiles, m * (6 * 20 * f + 12 * f),
+                      4 * (3 * n * f * 2 + 4 * n * f * 2) + m * (4 * 20 + 24), "hbm"))
+    if slot.tiles1 is not None:
+        tiled.append(("painn_message_bwd_tile_kernel (default)", msg_bwd_tiles, m * (12 * 20 * f + 30 * f),
+                      4 * (3 * n * f * 2 + 4 * n * f + 6 * n * f) + m * (8 * 20 + 40), "hbm"))
+    for name, fn, flops, nbytes, bound in tiled + [
+            ("painn_message_kernel (gather route)", msg, m * (6 * 20 * f + 12 * f), 4 * (3 * n * f * 2 + 4 * n * f * 2) + m * (4 * 20 + 24),
              "hbm"),
-            ("painn_message_bwd_kernel", msg_bwd, m * (12 * 20 * f + 30 * f),
+            ("painn_message_bwd_kernel (sender-parallel route)", msg_bwd, m * (12 * 20 * f + 30 * f),
              4 * (3 * n * f * 2 + 4 * n * f + 6 * n * f) + m * (8 * 20 + 40), "hbm"),
             ("dense_chain_kernel (3N,128)x(128,256)", gemm, 2 * 3 * n * 128 * 256, 4 * (3 * n * 128 + 128 * 256 + 3 * n * 256),
              "mfma"),
             ("dense_chain_kernel (N,128)x(128,128)x(128,384)", gemm2, 2 * n * 128 * (128 + 384),
-             4 * (n * 128 * 2 + 128 * 512 + n * 384), "mfma")):
+             4 * (n * 128 * 2 + 128 * 512 + n * 384), "mfma")]:
         ms = timer.time_ms(fn, 50)
         kernels[name] = {"avg_launch_us": ms * 1e3, "algorithmic_flops": flops, "algorithmic_bytes": nbytes,
                          "bound": bound, "tflops": flops / (ms * 1e-3) / 1e12, "gbs": nbytes / (ms * 1e-3) / 1e9,
