@@ -282,3 +282,29 @@ def test_reverse_message_tiles_against_gather_route_and_replays(monkeypatch, cut
                   _ffi.ptr(slot.w["conv0/w/F"]), _ffi.ptr(slot.ptr1), _ffi.ptr(slot.perm1), _ffi.ptr(slot.recv), slot.M,
                   _ffi.ptr(tl["table"]), tl["count"], 60, 40, 400, _ffi.ptr(slot.g_zp), _ffi.ptr(slot.g_vp), _ffi.ptr(slot.g_s),
                   None, _ffi.ptr(slot.g_d), _ffi.ptr(slot.g_rij), 0, _ffi.stream())
+
+
+@pytest.mark.parametrize("num_radial", [10, 12, 31])
+def test_tile_kernels_with_other_basis_sizes(num_radial):
+    """The generic-B builds of both tile kernels (the 20-function basis has builds of its own): 10 (rows not a multiple of
+    16 B: dword LDS-DMA in the forward kernel, two k groups of operand pieces), 12 (16-B pieces, two k groups) and 31 (the
+    largest basis with a free bias slot: four k groups) - energies against the NumPy oracle, every atom's force against the
+    analytic float64 reference, replays bit-identical."""
+    b = synth.md17_like_batch(num_graphs=6, seed=31)
+    p = synth.painn_params(seed=8, random_bias=True, num_radial=num_radial)
+    ba = {"num_radial": num_radial, "cutoff": 5.0, "envelope_exponent": 5}
+    energy = _model(p, bessel_basis=ba)
+    x = mol_inputs(b)
+    eng, force = energy.fused.energy_force(x)
+    slot = energy.fused.slot_of(x, grad=True)
+    assert slot.B == num_radial and slot.tiles0 is not None and slot.tiles1 is not None
+    pp32, pp64 = ko.to_dtype(p, np.float32), ko.to_dtype(p, np.float64)
+    ref = [ko.painn_forward(pp, ko.R(b["node_number"], b["node_splits"]), ko.R(b["node_coordinates"].astype(dt), b["node_splits"]),
+                            ko.R(b["edge_indices"], b["edge_splits"]), depth=3, equiv_method="eps", bessel_args=ba)
+           for pp, dt in ((pp32, np.float32), (pp64, np.float64))]
+    assert_rows_close(eng.cpu().numpy(), ref[0], ref[1], what="PaiNN energy, %d basis functions" % num_radial)
+    f32, f64 = (tfo.painn_energy_force(p, b, dt, equiv_method="eps", bessel_args=ba)[1] for dt in (torch.float32, torch.float64))
+    assert_forces_close(force.cpu().numpy(), f32, f64, b["node_splits"], what="PaiNN forces, %d basis functions" % num_radial)
+    for _ in range(40):
+        e2, f2 = energy.fused.energy_force(x)
+        assert torch.equal(e2, eng) and torch.equal(f2, force)
