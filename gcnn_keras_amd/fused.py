@@ -116,7 +116,8 @@ class WorkSet:
     direct-launch descriptor whose weight and work-buffer fields are filled once.  ``agg`` is zero between forwards (the
     node kernels re-zero the rows they consume, rows beyond a batch's N are never written), ``flags`` is zero unless a
     kernel flagged an error, so a recycled set needs no fill launch."""
-    __slots__ = ("n_cap", "m_cap", "g_cap", "recv", "send", "dist", "flags", "n", "x", "agg", "h", "desc", "stream_key")
+    __slots__ = ("n_cap", "m_cap", "g_cap", "recv", "send", "dist", "flags", "n", "x", "agg", "h", "desc", "stream_key",
+                 "_union")
 
     def __init__(self, n_cap, m_cap, g_cap, stream_key):
         dev = "cuda"
@@ -130,6 +131,26 @@ class WorkSet:
         self.agg = torch.zeros((n_cap, 128), dtype=torch.float32, device=dev)
         self.h = torch.empty((n_cap, 64), dtype=torch.float32, device=dev)
         self.desc = None
+        self._union = {}
+
+    def union(self, z_dtype):
+        """Input tensors of a launch group's union batch at this set's capacity (node numbers of ``z_dtype``, coordinates,
+        sample indices, both row splits) and the ``mp_concat_batches`` descriptor whose destination fields point at them:
+        made on first use, recycled with the set (a group of never-seen batches then allocates nothing)."""
+        got = self._union.get(z_dtype)
+        if got is None:
+            dev = "cuda"
+            z = torch.empty(self.n_cap, dtype=z_dtype, device=dev)
+            xyz = torch.empty((self.n_cap, 3), dtype=torch.float32, device=dev)
+            idx = torch.empty((self.m_cap, 2), dtype=torch.int64, device=dev)
+            ns = torch.empty(self.g_cap + 1, dtype=torch.int64, device=dev)
+            es = torch.empty(self.g_cap + 1, dtype=torch.int64, device=dev)
+            d = _ffi.ConcatDesc()
+            d.z_is_i64 = 1 if z_dtype == torch.int64 else 0
+            d.z, d.xyz, d.idx = z.data_ptr(), xyz.data_ptr(), idx.data_ptr()
+            d.node_splits, d.edge_splits = ns.data_ptr(), es.data_ptr()
+            got = self._union[z_dtype] = (z, xyz, idx, ns, es, d, ctypes.byref(d))
+        return got
 
 
 class WorkArena:
@@ -145,8 +166,16 @@ class WorkArena:
         self.max_free = max_free
         self.taken = self.made = 0
 
+    @staticmethod
+    def _bucket(x, unit):
+        # capacity classes an eighth of the size's power of two apart (never finer than ``unit``): batches of a dataset
+        # differ by a few per cent in N and M, launch groups of them by the same few per cent of a five times larger
+        # size - classes of a fixed width would give nearly every group a class of its own and the arena no hits
+        x = max(int(x), 1)
+        return _round_up(x, max(unit, (1 << (x.bit_length() - 1)) >> 3))
+
     def take(self, stream_key, n, m, g):
-        key = (stream_key, _round_up(n, self.N_UNIT), _round_up(m, self.M_UNIT), _round_up(g, self.G_UNIT))
+        key = (stream_key, self._bucket(n, self.N_UNIT), self._bucket(m, self.M_UNIT), self._bucket(g, self.G_UNIT))
         bucket = self.free.get(key)
         if bucket:
             self.taken += 1
@@ -219,7 +248,7 @@ class FusedSchnet:
         self._own_stream = value
 
     # ------------------------------------------------------------------------------------------------ binding
-    def bind(self, b, n, m, g, known_flags=None, arena=None):
+    def bind(self, b, n, m, g, known_flags=None, arena=None, work=None):
         """Attach a resident batch (dict of device tensors: z, xyz, idx, ns, es + host node splits) and take its work
         buffers - from ``arena`` (a route's ``WorkArena``: a recycled set of the size bucket, nothing allocated, nothing
         filled) or freshly allocated on the current stream.  ``known_flags``: the MP_FLAG_* word of the index list if a
@@ -230,7 +259,7 @@ class FusedSchnet:
         self.node_flags = (self.flags_arg & (3 | 64)) | i64
         dev = "cuda"
         if arena is not None:
-            ws = arena.take(_ffi.stream_handle(), n, m, g)
+            ws = work if work is not None else arena.take(_ffi.stream_handle(), n, m, g)   # (work: taken by the caller)
             self._work, self._arena = ws, arena
             self.recv, self.send, self.dist, self.flags = ws.recv, ws.send, ws.dist, ws.flags
             self.n, self.x, self.agg, self.h = ws.n, ws.x, ws.agg, ws.h
@@ -608,23 +637,18 @@ class SchnetGroup:
         ns_host = [np.asarray(x[0].row_splits_host(), dtype=np.int64) for x in inputs_list]
         sizes = [(int(x[0].values.shape[0]), int(x[2].values.shape[0]), x[0].nrows()) for x in inputs_list]
         n, m, g = (sum(t[i] for t in sizes) for i in range(3))
-        dev = z0.device
-        self.z = torch.empty(n, dtype=z0.dtype, device=dev)
-        self.xyz = torch.empty((n, 3), dtype=torch.float32, device=dev)
-        self.idx = torch.empty((m, 2), dtype=torch.int64, device=dev)
-        self.ns = torch.empty(g + 1, dtype=torch.int64, device=dev)
-        self.es = torch.empty(g + 1, dtype=torch.int64, device=dev)
-        d = _ffi.ConcatDesc()
-        d.k, d.z_is_i64 = k, 1 if z0.dtype == torch.int64 else 0
+        # the union's input tensors live in the work set (capacity of the size bucket; the kernels take addresses and the
+        # sizes n, m, g): a group of never-seen batches takes a recycled set and allocates nothing
+        work = route._arena.take(_ffi.stream_handle(), n, m, g)
+        self.z, self.xyz, self.idx, self.ns, self.es, d, self._desc_ref = work.union(z0.dtype)
+        d.k = k
         for b, (x, (nb, mb, gb)) in enumerate(zip(inputs_list, sizes)):
             node, xyz, idx = x
             src = d.src[b]
             src.z, src.xyz, src.idx = node.values.data_ptr(), xyz.values.data_ptr(), idx.values.data_ptr()
             src.node_splits, src.edge_splits = node.row_splits.data_ptr(), idx.row_splits.data_ptr()
             src.N, src.M, src.G = nb, mb, gb
-        d.z, d.xyz, d.idx = self.z.data_ptr(), self.xyz.data_ptr(), self.idx.data_ptr()
-        d.node_splits, d.edge_splits = self.ns.data_ptr(), self.es.data_ptr()
-        self.desc, self._desc_ref = d, ctypes.byref(d)
+        self.desc = d
         # host node splits of the union (row counts of the members: graphs without nodes at a member's end are dropped
         # from ITS result, as its own forward would do)
         offs, cat = 0, [np.zeros(1, np.int64)]
@@ -645,13 +669,17 @@ class SchnetGroup:
                 if plan._flags_host is not None:
                     flags = plan._flags_host
             known = None if (known is None or flags is None) else (known | int(flags))
-        self.concat()
+        if known is None:
+            self.concat()               # the bind's index pass reads the union
         self.slot = FusedSchnet(route._p, depth=route.depth, gauss_args=route.gauss, fast_softplus=route.fast_softplus,
                                 cfconv_flags=route.cfconv_flags, packed=route._packed)
         batch = {"z": self.z, "xyz": self.xyz, "idx": self.idx, "ns": self.ns, "es": self.es,
                  "ns_host": np.concatenate(cat)}
-        self.slot.bind(batch, n, m, g, known_flags=known, arena=route._arena)
-        self.slot._pre = self.concat
+        self.slot.bind(batch, n, m, g, known_flags=known, arena=route._arena, work=work)
+        # (not ``self.concat``: a bound method of the group inside its own slot is a reference cycle - the slot would be
+        #  freed by the cycle collector some time later, not when the group is dropped, and its work set would miss the arena)
+        concat, ref = _ffi.lib().mp_concat_batches, self._desc_ref
+        self.slot._pre = lambda: _ffi.check(concat(ref, _ffi.stream()))
         self.slot.calls = 0
         self.edges = m
 
@@ -835,7 +863,10 @@ class SchnetFusedRoute:
             out = slot.run_graph_fresh()
             if out is not None:
                 return grp.split(out)
-        return grp.split(slot.run_current(how).clone())
+        out = slot.run_current(how)
+        if how == "direct" and slot.calls == 1 and slot._work is not None:
+            return grp.split(slot.hand_out_static())   # first sight: the slot's result buffer becomes the callers' tensor
+        return grp.split(out.clone())
 
     def energy_force(self, inputs):
         """``(energy (G', 1), force (N, 3))`` with force = -dE/dx: fused forward + hand-written reverse pass, one HIP
