@@ -78,10 +78,10 @@ enum NodeMode { NODE_IN = 0, NODE_MID = 1, NODE_LAST = 2, NODE_UPD = 3 };
 // Epilogue helper: visit the wave's output elements.  C layout of 16x16x4: col = lane&15, row = 4*(lane>>4) + r.
 #define MP_FOR_OUT(cb, r, row, col, body)                             \
   _Pragma("unroll") for (int rb = 0; rb < RB; ++rb) {                 \
-    _Pragma("unroll") for (int cb = 0; cb < 2; ++cb) {                \
+    _Pragma("unroll") for (int cb = 0; cb < NCB; ++cb) {              \
       _Pragma("unroll") for (int r = 0; r < 4; ++r) {                 \
         const int row = 16 * rb + 4 * (lane >> 4) + r;                \
-        const int col = wave * 32 + 16 * cb + (lane & 15);            \
+        const int col = wave * (16 * NCB) + 16 * cb + (lane & 15);    \
         body                                                          \
       }                                                               \
     }                                                                 \
@@ -93,8 +93,23 @@ enum NodeMode { NODE_IN = 0, NODE_MID = 1, NODE_LAST = 2, NODE_UPD = 3 };
 // mp_schnet_node_pack_bf16_f32 images (three bf16 pieces per element: 1.5x the bytes, 2.67x the matrix rate).
 template <int MODE, int E, int RB, bool FAST, bool PACKED, bool SAVE = false, bool BF = false>
 __device__ __forceinline__ void schnet_node_body(const NodeArgs& a, int block, int nblocks) {
-  __shared__ float Xa[16 * RB * X_LD];
-  __shared__ float Xb[16 * RB * X_LD];
+  // activation tiles: FP32 rows (FP32 matrix instructions) or three bf16-piece planes written by the producer (BF builds:
+  // mp_node_tile.h, "the activation tile split once")
+  // BF builds run EIGHT waves on 16-column slices (NCB = 1): half the weight registers per wave (144 for the MID chain -
+  // no slice parked in AGPRs and fetched back in front of its MFMA), two waves per SIMD to hide each other's LDS and
+  // epilogue latencies; the pre-split tile is what makes the second wave per SIMD cheap (it reads pieces, it does not
+  // split the tile again).  The weight images are the same: slice (wave w of 4, column block cb) = slice (wave 2 w + cb of 8).
+  constexpr int NW = BF ? 8 : 4;
+  constexpr int NCB = BF ? 1 : 2;
+  constexpr int NT = 64 * NW;
+  constexpr int TNR = 16 * RB;
+  constexpr int TILE_BYTES = BF ? 3 * TNR * XP_LD * 2 : TNR * X_LD * 4;
+  __shared__ __attribute__((aligned(16))) unsigned char tile_a[TILE_BYTES];
+  __shared__ __attribute__((aligned(16))) unsigned char tile_b[TILE_BYTES];
+  float* const Xa = reinterpret_cast<float*>(tile_a);
+  float* const Xb = reinterpret_cast<float*>(tile_b);
+  unsigned short* const Pa = reinterpret_cast<unsigned short*>(tile_a);
+  unsigned short* const Pb = reinterpret_cast<unsigned short*>(tile_b);
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = tid >> 6;
@@ -107,8 +122,8 @@ __device__ __forceinline__ void schnet_node_body(const NodeArgs& a, int block, i
   // larger tiles: the next tile's rows are requested before the LAST big GEMM of the current tile (GEMM 3; GEMM 2 for the
   // input chain), into the registers that held the residual rows until the epilogue before it - no extra pressure
   constexpr bool LATE_STAGE = !EARLY_STAGE;
-  constexpr int SV_IN = (TN * E) / 256;      // floats per thread (NODE_IN: embedding rows)
-  constexpr int SV = (TN * F / 4) / 256;     // float4 per thread (aggregation rows)
+  constexpr int SV_IN = (TN * E) / NT;       // floats per thread (NODE_IN: embedding rows)
+  constexpr int SV = (TN * F / 4) / NT;      // float4 per thread (aggregation rows)
   float stg_in[MODE == NODE_IN ? SV_IN : 1];
   unsigned stg_ok = 0u;   // NODE_IN: bit j = element j of stg_in is a real embedding element (else 0)
   float4 stg[MODE == NODE_IN ? 1 : SV];
@@ -124,13 +139,13 @@ __device__ __forceinline__ void schnet_node_body(const NodeArgs& a, int block, i
       if (a.numbers_i64) {
 #pragma unroll
         for (int j = 0; j < SV_IN; ++j) {
-          const int64_t node = n0 + (tid + j * 256) / E;
+          const int64_t node = n0 + (tid + j * NT) / E;
           z[j] = static_cast<int>(static_cast<const int64_t*>(a.numbers)[(live && node < a.N) ? node : n_last]);
         }
       } else {
 #pragma unroll
         for (int j = 0; j < SV_IN; ++j) {
-          const int64_t node = n0 + (tid + j * 256) / E;
+          const int64_t node = n0 + (tid + j * NT) / E;
           // Keras Embedding casts its input to int32
           z[j] = static_cast<int>(static_cast<const float*>(a.numbers)[(live && node < a.N) ? node : n_last]);
         }
@@ -138,20 +153,20 @@ __device__ __forceinline__ void schnet_node_body(const NodeArgs& a, int block, i
 #pragma unroll
       for (int j = 0; j < SV_IN; ++j) {
         const int zc = z[j] < 0 ? 0 : (z[j] >= a.vocab ? a.vocab - 1 : z[j]);
-        stg_in[j] = a.emb[static_cast<int64_t>(zc) * E + (tid + j * 256) % E];
+        stg_in[j] = a.emb[static_cast<int64_t>(zc) * E + (tid + j * NT) % E];
       }
       // validity is applied when the registers are written to LDS (stage_store): a select here would make the wave wait
       // for the embedding elements before it requests its weight slices
       stg_ok = 0u;
 #pragma unroll
       for (int j = 0; j < SV_IN; ++j) {
-        const int64_t node = n0 + (tid + j * 256) / E;
+        const int64_t node = n0 + (tid + j * NT) / E;
         if (live && node < a.N && z[j] >= 0 && z[j] < a.vocab) stg_ok |= 1u << j;
       }
     } else {
 #pragma unroll
       for (int j = 0; j < SV; ++j) {
-        const int i = tid + j * 256;
+        const int i = tid + j * NT;
         const int r = i / (F / 4), k4 = i % (F / 4);
         const int64_t node = n0 + r;
         float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -165,19 +180,45 @@ __device__ __forceinline__ void schnet_node_body(const NodeArgs& a, int block, i
     }
   };
   auto stage_store = [&]() {
-    if constexpr (MODE == NODE_IN) {
+    if constexpr (MODE == NODE_IN && BF) {
+      static_assert(MODE != NODE_IN || !BF || SV_IN % 2 == 0, "element pairs");
+#pragma unroll
+      for (int j = 0; j + 1 < SV_IN; j += 2) {   // elements j, j + 1 of a thread: one column, rows NT / E apart
+        const int i = tid + j * NT;
+        put_split_rows<TNR>(Pa, i / E, (i + NT) / E, i % E, ((stg_ok >> j) & 1u) ? stg_in[j] : 0.0f,
+                            ((stg_ok >> (j + 1)) & 1u) ? stg_in[j + 1] : 0.0f);
+      }
+    } else if constexpr (MODE == NODE_IN) {
 #pragma unroll
       for (int j = 0; j < SV_IN; ++j) {
-        const int i = tid + j * 256;
+        const int i = tid + j * NT;
         Xa[(i / E) * X_LD + (i % E)] = ((stg_ok >> j) & 1u) ? stg_in[j] : 0.0f;
+      }
+    } else if constexpr (BF) {
+#pragma unroll
+      for (int j = 0; j < SV; ++j) {
+        const int i = tid + j * NT;
+        put_split4<TNR>(Pa, i / (F / 4), 4 * (i % (F / 4)), stg[j]);
       }
     } else {
 #pragma unroll
       for (int j = 0; j < SV; ++j) {
-        const int i = tid + j * 256;
+        const int i = tid + j * NT;
         float* d = Xa + (i / (F / 4)) * X_LD + 4 * (i % (F / 4));
         d[0] = stg[j].x; d[1] = stg[j].y; d[2] = stg[j].z; d[3] = stg[j].w;
       }
+    }
+  };
+  // BF builds: an epilogue hands its output tile on as bf16 pieces (put_split_acc)
+  float ov[BF ? RB : 1][NCB][4];
+  auto put_tile = [&](unsigned short* P) {
+    if constexpr (BF) {
+#pragma unroll
+      for (int rb = 0; rb < RB; ++rb)
+#pragma unroll
+        for (int cb = 0; cb < NCB; ++cb) {
+          put_split_acc<TNR>(P, lane, 16 * rb + 4 * (lane >> 4), wave * (16 * NCB) + 16 * cb + (lane & 15), ov[rb][cb]);
+        }
     }
   };
   stage_load(block);
@@ -186,32 +227,33 @@ __device__ __forceinline__ void schnet_node_body(const NodeArgs& a, int block, i
   constexpr int K1 = MODE == NODE_IN ? E : F;
   constexpr int K3 = (MODE == NODE_IN || MODE == NODE_UPD) ? (BF ? 32 : 4) : F;   // (unused slices: smallest legal size)
   constexpr int K4 = MODE == NODE_LAST ? F : (BF ? 32 : 4);
-  std::conditional_t<BF, WSliceBf<K1, 2>, float[2][K1 / 4]> w_first;    // IN: W0 ; MID/LAST: W2
-  std::conditional_t<BF, WSliceBf<F, 2>, float[2][F / 4]> w_second;     // IN: Wx ; MID/LAST: W3
-  std::conditional_t<BF, WSliceBf<K3, 2>, float[2][K3 / 4]> w_third;    // MID: Wx ; LAST: Wl0
-  std::conditional_t<BF, WSliceBf<K4, 1>, float[1][K4 / 4]> w_fourth;   // LAST: Wl1 (16 columns per wave)
-  float bias_first[2], bias_second[2], bias_third[2], bias_fourth;
+  std::conditional_t<BF, WSliceBf<K1, NCB>, float[NCB][K1 / 4]> w_first;    // IN: W0 ; MID/LAST: W2
+  std::conditional_t<BF, WSliceBf<F, NCB>, float[NCB][F / 4]> w_second;     // IN: Wx ; MID/LAST: W3
+  std::conditional_t<BF, WSliceBf<K3, NCB>, float[NCB][K3 / 4]> w_third;    // MID: Wx ; LAST: Wl0
+  std::conditional_t<BF, WSliceBf<K4, 1>, float[1][K4 / 4]> w_fourth;       // LAST: Wl1 (16 columns per wave, waves 0-3)
+  float bias_first[NCB], bias_second[NCB], bias_third[NCB], bias_fourth;
+  const bool has_fourth = wave < 4;   // (wave-uniform) the 64 columns of GEMM 4 are four 16-column slices
 #define MP_LOAD_W(KK, NCB, PTR, UU, DST)                                          \
   if constexpr (BF) load_w_bf<KK, NCB>(PTR, wave, lane, DST);                     \
   else load_w<KK, NCB, PACKED>(PTR, UU, wave, lane, DST)
 #define MP_GEMM(KK, NCB, XS, WW, ACC)                                             \
-  if constexpr (BF) gemm_tile_bf<KK, NCB, RB>(XS, lane, WW, ACC);                 \
+  if constexpr (BF) gemm_tile_pre<KK, NCB, RB, MODE != NODE_LAST>(reinterpret_cast<const unsigned short*>(XS), lane, WW, ACC); \
   else gemm_tile<KK, NCB, RB>(XS, lane, WW, ACC)
   if constexpr (MODE == NODE_IN) {
-    MP_LOAD_W(E, 2, a.W0, F, w_first);
-    MP_LOAD_W(F, 2, a.Wx, F, w_second);
+    MP_LOAD_W(E, NCB, a.W0, F, w_first);
+    MP_LOAD_W(F, NCB, a.Wx, F, w_second);
   } else {
-    MP_LOAD_W(F, 2, a.W2, F, w_first);
-    MP_LOAD_W(F, 2, a.W3, F, w_second);
-    if constexpr (MODE == NODE_MID) { MP_LOAD_W(F, 2, a.Wx, F, w_third); }
+    MP_LOAD_W(F, NCB, a.W2, F, w_first);
+    MP_LOAD_W(F, NCB, a.W3, F, w_second);
+    if constexpr (MODE == NODE_MID) { MP_LOAD_W(F, NCB, a.Wx, F, w_third); }
     if constexpr (MODE == NODE_LAST) {
-      MP_LOAD_W(F, 2, a.Wl0, F, w_third);
-      MP_LOAD_W(F, 1, a.Wl1, 64, w_fourth);
+      MP_LOAD_W(F, NCB, a.Wl0, F, w_third);
+      if (has_fourth) { MP_LOAD_W(F, 1, a.Wl1, 64, w_fourth); }
     }
   }
 #pragma unroll
-  for (int cb = 0; cb < 2; ++cb) {
-    const int col = wave * 32 + 16 * cb + (lane & 15);
+  for (int cb = 0; cb < NCB; ++cb) {
+    const int col = wave * (16 * NCB) + 16 * cb + (lane & 15);
     if constexpr (MODE == NODE_IN) {
       bias_first[cb] = a.b0 ? a.b0[col] : 0.0f;
       bias_second[cb] = 0.0f;
@@ -222,7 +264,7 @@ __device__ __forceinline__ void schnet_node_body(const NodeArgs& a, int block, i
       bias_third[cb] = (MODE == NODE_LAST && a.bl0) ? a.bl0[col] : 0.0f;
     }
   }
-  bias_fourth = (MODE == NODE_LAST && a.bl1) ? a.bl1[wave * 16 + (lane & 15)] : 0.0f;
+  bias_fourth = (MODE == NODE_LAST && a.bl1 && has_fourth) ? a.bl1[wave * 16 + (lane & 15)] : 0.0f;
 
 #ifdef MP_NODE_DIAG
   unsigned long long dsum[8] = {0, 0, 0, 0, 0, 0, 0, 0};
@@ -238,13 +280,13 @@ __device__ __forceinline__ void schnet_node_body(const NodeArgs& a, int block, i
     MP_NSTAMP(0)
 
     if constexpr (EARLY_STAGE) stage_load(tile + nblocks);  // next tile, in flight during the GEMMs
-    floatx4 acc[RB][2];
+    floatx4 acc[RB][NCB];
     // residual rows of n: requested well before the epilogue that adds them - never inside it, where every load would
     // have to wait behind the previous element's store to the same array (measured at 225 k nodes: 24 k of a tile's 48 k
     // cycles).  The 16-node build asks at tile start (hidden under GEMM 1 and 2), the larger tiles right before GEMM 2
     // so that the values are not live during GEMM 1.
     constexpr bool N_EARLY = RB == 1;
-    float n_res[RB][2][4];
+    float n_res[RB][NCB][4];
     if constexpr (MODE != NODE_IN && N_EARLY) {
       MP_FOR_OUT(cb, r, row, col, {
         n_res[rb][cb][r] = (node0 + row < a.N) ? a.n[(node0 + row) * F + col] : 0.0f;
@@ -253,9 +295,9 @@ __device__ __forceinline__ void schnet_node_body(const NodeArgs& a, int block, i
     // ---- GEMM 1: IN: n = emb @ W0 + b0 ; MID/LAST: t = ssp(agg @ W2 + b2) ---------------------------------------
 #define MP_ZERO_ACC                                              \
   _Pragma("unroll") for (int rb = 0; rb < RB; ++rb)              \
-      _Pragma("unroll") for (int cb = 0; cb < 2; ++cb) acc[rb][cb] = floatx4{0.f, 0.f, 0.f, 0.f};
+      _Pragma("unroll") for (int cb = 0; cb < NCB; ++cb) acc[rb][cb] = floatx4{0.f, 0.f, 0.f, 0.f};
     MP_ZERO_ACC
-    MP_GEMM(K1, 2, Xa, w_first, acc);
+    MP_GEMM(K1, NCB, Xa, w_first, acc);
     MP_NSTAMP(1)
     MP_FOR_OUT(cb, r, row, col, {
       float v = acc[rb][cb][r] + bias_first[cb];
@@ -266,11 +308,13 @@ __device__ __forceinline__ void schnet_node_body(const NodeArgs& a, int block, i
       } else if constexpr (MODE != NODE_IN) {
         v = ssp<FAST>(v);
       }
-      Xb[row * X_LD + col] = v;
+      if constexpr (BF) ov[rb][cb][r] = v;
+      else Xb[row * X_LD + col] = v;
       if constexpr (MODE == NODE_IN) {
         if (node0 + row < a.N) a.n[(node0 + row) * F + col] = v;
       }
     })
+    put_tile(Pb);
     __syncthreads();
     MP_NSTAMP(2)
 
@@ -282,7 +326,7 @@ __device__ __forceinline__ void schnet_node_body(const NodeArgs& a, int block, i
         n_res[rb][cb][r] = (node0 + row < a.N) ? a.n[(node0 + row) * F + col] : 0.0f;
       })
     }
-    MP_GEMM(F, 2, Xb, w_second, acc);
+    MP_GEMM(F, NCB, Xb, w_second, acc);
     MP_NSTAMP(3)
     if constexpr (MODE == NODE_IN) {
       MP_FOR_OUT(cb, r, row, col, {
@@ -295,16 +339,20 @@ __device__ __forceinline__ void schnet_node_body(const NodeArgs& a, int block, i
         const float nn = n_res[rb][cb][r] + y;  // LazyAdd([node, x])
         if (ok && MODE == NODE_MID) a.n[(node0 + row) * F + col] = nn;
         if (ok && MODE == NODE_UPD) a.n_out[(node0 + row) * F + col] = nn;
-        if constexpr (MODE != NODE_UPD) Xa[row * X_LD + col] = nn;
+        if constexpr (MODE != NODE_UPD) {
+          if constexpr (BF) ov[rb][cb][r] = nn;
+          else Xa[row * X_LD + col] = nn;
+        }
       })
       if constexpr (MODE != NODE_UPD) {
+      put_tile(Pa);
       __syncthreads();
       MP_NSTAMP(4)
 
       // ---- GEMM 3: MID: x = n @ Wx ; LAST: u = ssp(n @ Wl0 + bl0) ----------------------------------------------
       MP_ZERO_ACC
       if constexpr (LATE_STAGE) stage_load(tile + nblocks);
-      MP_GEMM(K3, 2, Xa, w_third, acc);
+      MP_GEMM(K3, NCB, Xa, w_third, acc);
       MP_NSTAMP(5)
       if constexpr (MODE == NODE_MID) {
         MP_FOR_OUT(cb, r, row, col, {
@@ -320,10 +368,13 @@ __device__ __forceinline__ void schnet_node_body(const NodeArgs& a, int block, i
           } else {
             v = ssp<FAST>(v);
           }
-          Xb[row * X_LD + col] = v;
+          if constexpr (BF) ov[rb][cb][r] = v;
+          else Xb[row * X_LD + col] = v;
         })
+        put_tile(Pb);
         __syncthreads();
         // ---- GEMM 4 (LAST): h = ssp(u @ Wl1 + bl1), 64 output columns = 16 per wave ------------------------------
+        if (has_fourth) {
         floatx4 acc4[RB][1];
 #pragma unroll
         for (int rb = 0; rb < RB; ++rb) acc4[rb][0] = floatx4{0.f, 0.f, 0.f, 0.f};
@@ -346,6 +397,7 @@ __device__ __forceinline__ void schnet_node_body(const NodeArgs& a, int block, i
               a.h[(node0 + row) * 64 + col] = v;
             }
           }
+        }
       }
       }
     }
@@ -364,7 +416,7 @@ __device__ __forceinline__ void schnet_node_body(const NodeArgs& a, int block, i
 template <int MODE, int E, int RB, bool FAST, bool PACKED, bool SAVE, bool BF = false>
 // (the SAVE builds of the energy + force pass need a few registers more than 256, the bf16-piece builds hold 1.5x the
 // weight registers: one workgroup per CU instead of a scratch segment, which every launch of the kernel would pay for)
-__global__ __launch_bounds__(256, (MODE != NODE_LAST && !SAVE && !BF) ? 2 : 1) void schnet_node_kernel(NodeArgs a) {
+__global__ __launch_bounds__(BF ? 512 : 256, (MODE != NODE_LAST && !SAVE && !BF) ? 2 : 1) void schnet_node_kernel(NodeArgs a) {
   schnet_node_body<MODE, E, RB, FAST, PACKED, SAVE, BF>(a, blockIdx.x, gridDim.x);
 }
 
@@ -372,7 +424,7 @@ __global__ __launch_bounds__(256, (MODE != NODE_LAST && !SAVE && !BF) ? 2 : 1) v
 // (index shift, receiver/sender split, flags, distance) are independent, and at QM9 batch sizes each alone fills less
 // than half of the chip for ~5 us - so one launch runs both, on disjoint workgroups (role by block index).
 template <int E, bool FAST, bool LDS_SPLITS, bool PACKED, bool BF = false>
-__global__ __launch_bounds__(256) void schnet_stage0_kernel(NodeArgs a, mp_prep::EdgePrepArgs p, int node_blocks) {
+__global__ __launch_bounds__(BF ? 512 : 256) void schnet_stage0_kernel(NodeArgs a, mp_prep::EdgePrepArgs p, int node_blocks) {
   if (static_cast<int>(blockIdx.x) < node_blocks) {
     schnet_node_body<NODE_IN, E, 1, FAST, PACKED, false, BF>(a, blockIdx.x, node_blocks);
   } else {
@@ -500,7 +552,7 @@ int launch_node_impl(NodeArgs a, hipStream_t s, const char* what) {
   a.ntiles = static_cast<int>((a.N + 15) / 16);
   const int cap = BF ? 256 : 512;   // bf16-piece builds: one workgroup per CU
   const int grid = a.ntiles < cap ? a.ntiles : cap;
-  schnet_node_kernel<MODE, E, 1, FAST, PACKED, SAVE, BF><<<grid, 256, 0, s>>>(a);
+  schnet_node_kernel<MODE, E, 1, FAST, PACKED, SAVE, BF><<<grid, BF ? 512 : 256, 0, s>>>(a);
   return mp::check_launch(what);
 }
 
@@ -574,8 +626,10 @@ template <int E>
 void launch_stage0(const NodeArgs& a, const mp_prep::EdgePrepArgs& p, int node_blocks, unsigned grid, int flags_arg,
                    hipStream_t s) {
   if ((flags_arg & 66) == 66) {   // bf16-piece weight images
-    if (flags_arg & 1) schnet_stage0_kernel<E, true, true, true, true><<<grid, 256, 0, s>>>(a, p, node_blocks);
-    else schnet_stage0_kernel<E, false, true, true, true><<<grid, 256, 0, s>>>(a, p, node_blocks);
+    // (eight-wave node workgroups; the edge-preparation workgroups of the launch are block-size agnostic: half as many)
+    const unsigned grid8 = static_cast<unsigned>(node_blocks) + (grid - static_cast<unsigned>(node_blocks) + 1) / 2;
+    if (flags_arg & 1) schnet_stage0_kernel<E, true, true, true, true><<<grid8, 512, 0, s>>>(a, p, node_blocks);
+    else schnet_stage0_kernel<E, false, true, true, true><<<grid8, 512, 0, s>>>(a, p, node_blocks);
     return;
   }
   switch (flags_arg & 3) {

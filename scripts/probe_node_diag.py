@@ -18,14 +18,22 @@ agg = torch.randn(n, 128, device="cuda"); nn_ = torch.randn(n, 128, device="cuda
 W2, b2 = dev(p["interaction0/dense2/kernel"]), dev(p["interaction0/dense2/bias"])
 W3, b3 = dev(p["interaction0/dense3/kernel"]), dev(p["interaction0/dense3/bias"])
 Wx = dev(p["interaction1/dense1/kernel"])
+flags = 1
+if len(sys.argv) > 2 and sys.argv[2] == "bf":     # the forward's default build: bf16-piece weight images (flags 2 | 64)
+    def pack(w):
+        out = torch.empty(w.numel() * 3 // 2, device="cuda")
+        _ffi.call("mp_schnet_node_pack_bf16_f32", _ffi.ptr(w), int(w.shape[0]), int(w.shape[1]), _ffi.ptr(out), _ffi.stream())
+        return out
+    W2, W3, Wx = pack(W2), pack(W3), pack(Wx)
+    flags = 1 | 2 | 64
 def launch():
     _ffi.call("mp_schnet_node_update_f32", _ffi.ptr(agg), n, _ffi.ptr(W2), _ffi.ptr(b2), _ffi.ptr(W3), _ffi.ptr(b3),
-              _ffi.ptr(nn_), _ffi.ptr(Wx), _ffi.ptr(x), 1, _ffi.stream())
+              _ffi.ptr(nn_), _ffi.ptr(Wx), _ffi.ptr(x), flags, _ffi.stream())
 ms = _HipTimer().time_ms(launch, 10)
 lib = _ffi.lib(); out = (ctypes.c_ulonglong * 8)()
 lib.mp_debug_node_diag(out); launch(); torch.cuda.synchronize(); lib.mp_debug_node_diag(out)
 v = np.array(list(out), dtype=np.float64)
 names = ["stage+barrier", "gemm1", "epi1+barrier", "gemm2", "epi2+barrier", "gemm3", "epi3+barrier", "loop"]
-tiles = (n + 31) // 32 if n > 16384 else (n + 15) // 16
+tiles = (n + 15) // 16
 print("N=%d node MID %.1f us; cycles per tile (thread 0 of each workgroup):" % (n, ms * 1e3))
 print("  " + "  ".join("%s %.0f" % (nm, x_ / tiles) for nm, x_ in zip(names, v)), " total %.0f" % (v.sum() / tiles))
