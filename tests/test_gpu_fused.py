@@ -563,6 +563,60 @@ def test_launch_group_serves_several_batches_from_one_launch_sequence():
     model.fused.check_flags()
 
 
+def test_first_sight_groups_recycle_their_work_set_and_union_tensors():
+    """Never-seen batches served as launch groups (``model.predict`` over a dataset, five batches per launch sequence): the
+    union's input tensors and the concatenation descriptor live in the work set, a dropped group hands its set back at once
+    (no reference cycle between group and slot), the next group of the same size class takes it - nothing allocated - and
+    gets the oracle's rows, not the previous group's; the first result is the slot's own buffer (no copy launch)."""
+    import gc
+    from gcnn_keras_amd.data.packer import BatchPacker
+    from gcnn_keras_amd.literature import Schnet
+    p = synth.schnet_params(seed=7, random_bias=True)
+    model = Schnet.make_model(depth=3)
+    model.set_weights(list(p.values()))
+    items = [{"name": "node_number", "ragged": True, "dtype": "float32"},
+             {"name": "node_coordinates", "ragged": True, "dtype": "float32"},
+             {"name": "edge_indices", "ragged": True, "dtype": "int64"}]
+    packer = BatchPacker(items, index_item="edge_indices", node_item="node_number", slots=8)
+
+    def graph_list(b):
+        ns, es = b["node_splits"], b["edge_splits"]
+        return [{"node_number": b["node_number"][ns[g]:ns[g + 1]], "node_coordinates": b["node_coordinates"][ns[g]:ns[g + 1]],
+                 "edge_indices": b["edge_indices"][es[g]:es[g + 1]]} for g in range(len(ns) - 1)]
+
+    def oracle(b):
+        return ko.schnet_forward(p, ko.R(b["node_number"], b["node_splits"]), ko.R(b["node_coordinates"], b["node_splits"]),
+                                 ko.R(b["edge_indices"], b["edge_splits"]), depth=3)
+
+    gc.disable()                                     # a cycle would be hidden by a collection that happens to run
+    try:
+        route = model.fused
+        made = []
+        for rnd in range(3):
+            batches = [synth.qm9_like_batch(num_graphs=12, seed=100 + 4 * rnd + k) for k in range(4)]
+            packed = [packer.pack(graph_list(b)) for b in batches]
+            for pb in packed:
+                pb.wait(torch.cuda.current_stream())
+            ins = [[pb["node_number"], pb["node_coordinates"], pb["edge_indices"]] for pb in packed]
+            got = route.call_group(ins)
+            assert route.last == "direct"
+            torch.cuda.synchronize()
+            for k, b in enumerate(batches):
+                assert_rows_close(got[k].cpu().numpy(), oracle(b), what="first-sight group %d, member %d" % (rnd, k))
+            grp = next(iter(route._groups.values()))
+            assert got[0].untyped_storage().data_ptr() == grp.slot.out.untyped_storage().data_ptr()   # handed out, not copied
+            del grp
+            route._groups.clear()                    # the group is dropped: its work set must be back in the arena NOW
+            made.append(route._arena.made)
+            assert sum(len(v) for v in route._arena.free.values()) >= 1
+            del got, ins, packed
+        assert made[0] == made[1] == made[2], made   # rounds 2 and 3 took round 1's set (same size class)
+        assert route._arena.taken >= 2
+    finally:
+        gc.enable()
+    route.check_flags()
+
+
 def test_schnet_forward_harness_launch_groups_in_flight():
     """``SchnetForward(group=k, in_flight=n)`` (what ``bench.py`` times by default): n launch groups of k independent batches
     each; every member's rows equal a lone forward's (2e-6: the cfconv boundary sums pair differently in the union), the

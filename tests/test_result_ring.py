@@ -59,3 +59,18 @@ def test_a_caller_holding_only_the_storage_blocks_the_set():
     del storage
     got = ring.acquire(make, capture)
     assert got is not None and got[1] is g1
+
+
+def test_work_arena_size_classes():
+    """Capacity classes of the route's work-set arena: an eighth of the size's power of two apart, never finer than the
+    unit, never below the request - batches of a dataset (a few per cent apart in N and M) share classes at every scale."""
+    from gcnn_keras_amd.fused import WorkArena
+    b = WorkArena._bucket
+    for x in (1, 17, 511, 512, 513, 2301, 11573, 26190, 130950, 2_000_000):
+        for unit in (64, 512, 8192):
+            step = max(unit, (1 << (x.bit_length() - 1)) >> 3)
+            c = b(x, unit)
+            assert c >= x and c % step == 0 and c - x < step
+    assert b(11400, 512) == b(11573, 512) == b(11700, 512) == 12288      # launch groups of five config-2 batches
+    assert b(128000, 8192) == b(131000, 8192) == 131072
+    assert b(0, 512) == 512 and b(2301, 512) == 2560 and b(26190, 8192) == 32768
