@@ -692,7 +692,10 @@ int mp_schnet_stage0_f32(const float* numbers, int64_t N, const float* emb, int 
   a.numbers = numbers; a.numbers_i64 = (flags_arg & 256) ? 1 : 0;
   a.emb = emb; a.vocab = vocab; a.W0 = W0; a.b0 = b0; a.Wx = Wx; a.n = n_out; a.x = x_out;
   mp_prep::EdgePrepArgs p{idx, M, node_splits, edge_splits, G, N, xyz, recv, send, dist, flags};
-  const int node_blocks = a.ntiles;
+  // node chain: persistent over the tiles beyond one workgroup per CU (a workgroup's weight slices - 72 KB as bf16 pieces -
+  // are loaded once for its tiles, not once per tile: launch groups of five batches have 720 tiles)
+  const int node_cap = ((flags_arg & 66) == 66) ? 256 : 512;   // eight-wave bf16-piece build: one workgroup per CU
+  const int node_blocks = a.ntiles < node_cap ? a.ntiles : node_cap;
   const int edge_blocks = static_cast<int>(mp::grid_for(M));
   hipStream_t s = mp::as_stream(stream);
   const unsigned grid = static_cast<unsigned>(node_blocks + edge_blocks);
