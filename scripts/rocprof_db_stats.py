@@ -9,16 +9,24 @@ import sys
 
 def short(name):
     name = name.replace("(anonymous namespace)::", "").replace("void ", "")
+    tail = name[name.rfind(" [grid "):] if " [grid " in name else ""
+    if tail:
+        name = name[:-len(tail)]
     cut = name.find("(")
-    return (name if cut < 0 else name[:cut])[:70]
+    return (name if cut < 0 else name[:cut])[:70] + tail
 
 
 def main():
     db_path, out_path = sys.argv[1], sys.argv[2]
     title = sys.argv[3] if len(sys.argv) > 3 else db_path
     cur = sqlite3.connect(db_path).cursor()
-    rows = cur.execute("select name, count(*), avg(end - start), min(end - start), max(end - start), sum(end - start) "
-                       "from kernels group by name order by 6 desc").fetchall()
+    # --by-grid: one line per (kernel, grid size) - tells a launch group's union launches (e.g. 1024 workgroups) from the
+    # single-batch launches of the same kernel in the same run
+    cols = [r[1] for r in cur.execute("pragma table_info(kernels)").fetchall()]
+    by_grid = "--by-grid" in sys.argv and "grid_x" in cols
+    key = "name || ' [grid ' || grid_x || ']'" if by_grid else "name"
+    rows = cur.execute("select %s, count(*), avg(end - start), min(end - start), max(end - start), sum(end - start) "
+                       "from kernels group by 1 order by 6 desc" % key).fetchall()
     total = sum(r[5] for r in rows) or 1
     with open(out_path, "w") as f:
         f.write("# %s\n# source: rocprofv3 --kernel-trace --stats (%s), MI355X\n" % (title, db_path))
