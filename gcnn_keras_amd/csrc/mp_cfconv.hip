@@ -926,7 +926,16 @@ int cfconv_dispatch(CfconvArgs args, bool gauss, int flags, hipStream_t s) {
   // several tiles: 8 waves (256 registers each, sender rows loaded late) from 4096 tiles on - measured 812 vs 928 us at
   // 2.5 M edges, 87 vs 93 us at 0.2 M - and 4 waves (one tile per wave spread over more CUs) below.  Flag bit 2 forces
   // 8 waves, bit 3 forces 4, bit 4 selects the 256-register 4-wave build (Gauss variant, 20 bins).
-  int waves = args.ntiles >= 4096 ? 8 : 4;
+  // Between the regimes the launch is a whole number of ROUNDS over the resident waves (256 workgroups: 1024 waves of the
+  // 4-wave build, 2048 of the 8-wave one), and a round of the 8-wave build - two waves sharing a SIMD - costs 1.85 rounds
+  // of the 4-wave build (4093 tiles, a launch group of five config-2 batches: 4 rounds x 8.35 us against 2 x 15.45 us;
+  // 3274 tiles: 30.5 against 29.1 us; 2456 tiles: 24.3 against 26.5 us; 4910 tiles: 8 waves 7 % slower).  From 3072 tiles
+  // on the build with the smaller rounds x cost product runs; far above, the 8-wave build's 0.925 wins.
+  int waves = 4;
+  if (args.ntiles >= 3072) {
+    const int r4 = (args.ntiles + 1023) / 1024, r8 = (args.ntiles + 2047) / 2048;
+    waves = (37 * r8 < 20 * r4) ? 8 : 4;
+  }
   if (flags & 4) waves = 8;
   if (flags & 8) waves = 4;
   if (!(fast && (args.B == 20 || args.B == 25))) waves = 4;   // no spill-free 8-wave build for these (launch_by_basis)

@@ -596,7 +596,15 @@ class FusedSchnet:
         gemm1_cycles = 2 * 4 * 6 * 32 if bins == 20 else ((bins + 2) // 2) * 4 * 64
         mfma_cycles = tiles * (gemm1_cycles + 8 * 4 * 6 * 32)
         pipe_busy = mfma_cycles / (1024 * 2.4e9 * ms * 1e-3)
-        return {"bound": "mfma", "kernel": "cfconv_fused_kernel<4,gauss> (SchNetCFconv, one interaction block)",
+        # the build cfconv_dispatch (csrc/mp_cfconv.hip) picks for this launch: eight waves per workgroup when the rounds x cost
+        # product favours them (from 3072 tiles on), forced by flag bit 2 / 3; fast softplus and 20 / 25 bins only
+        waves = 4
+        if tiles >= 3072 and 37 * ((tiles + 2047) // 2048) < 20 * ((tiles + 1023) // 1024):
+            waves = 8
+        waves = 8 if self.flags_arg & 4 else (4 if self.flags_arg & 8 else waves)
+        if not (self.flags_arg & 1 and bins in (20, 25)):
+            waves = 4
+        return {"bound": "mfma", "kernel": "cfconv_fused_kernel<%d,gauss> (SchNetCFconv, one interaction block)" % waves,
                 "achieved": achieved, "peak": mfma_peak_tf, "unit": "TFLOP/s", "frac": achieved / mfma_peak_tf,
                 "traffic": None, "avg_launch_us": ms * 1e3, "algorithmic_flops_per_launch": flops,
                 "algorithmic_bytes_per_launch": alg_bytes,
