@@ -139,6 +139,14 @@ def cpu_baseline(batch, params, depth):
             "legs": legs}
 
 
+def _kernel_entries(kernels, kernel_name):
+    """Entries of a counter summary that belong to ``kernel_name`` ("cfconv_fused_kernel<8,gauss> ..."): the build named there
+    first (a launch-group run holds the 8-wave union launches next to 4-wave single-batch launches of the same kernel), any
+    build of the kernel otherwise."""
+    exact = [(k, v) for k, v in kernels.items() if k.split(",")[0] in kernel_name]
+    return exact or [(k, v) for k, v in kernels.items() if k.split("<")[0] in kernel_name]
+
+
 def pmc_traffic(kernel_name, graphs):
     """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes (profiles/*pmc*.json):
     FETCH_SIZE and WRITE_SIZE collected in separate runs of this same command; FETCH doubled as the microarch guide
@@ -149,8 +157,8 @@ def pmc_traffic(kernel_name, graphs):
         try:
             for entry in json.load(open(path)):
                 if want and entry["label"].startswith(want):
-                    for k, v in entry["kernels"].items():
-                        if k.split("<")[0] in kernel_name:
+                    for k, v in _kernel_entries(entry["kernels"], kernel_name):
+                        if True:
                             raw_f, raw_w = v["FETCH_SIZE_KB_median"] * 1024, v["WRITE_SIZE_KB_median"] * 1024
                             return {"traffic": 2 * raw_f + raw_w,
                                     "traffic_detail": {"source": os.path.basename(path), "fetch_bytes_raw": raw_f,
@@ -172,8 +180,8 @@ def pmc_matrix_pipe(kernel_name, graphs, avg_launch_us):
         try:
             for entry in json.load(open(path)):
                 if want and entry["label"].startswith(want):
-                    for k, v in entry["kernels"].items():
-                        if k.split("<")[0] in kernel_name and v.get("SQ_VALU_MFMA_BUSY_CYCLES"):
+                    for k, v in _kernel_entries(entry["kernels"], kernel_name):
+                        if v.get("SQ_VALU_MFMA_BUSY_CYCLES"):
                             busy = v["SQ_VALU_MFMA_BUSY_CYCLES"]
                             out = {"source": os.path.basename(path), "SQ_VALU_MFMA_BUSY_CYCLES": busy,
                                    "SQ_INSTS_VALU": v.get("SQ_INSTS_VALU"),
