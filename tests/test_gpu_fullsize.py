@@ -48,6 +48,38 @@ def test_config4_shard_graph_independence_and_c_oracle(shard_batch):
         assert_rows_close(whole[3000:5000], ref, what="config-4 shard rows 3000-5000 vs the C oracle")
 
 
+def test_default_bench_launch_group_rows_at_full_size():
+    """What ``bench.py`` times by default: a launch group of FIVE independent 128-graph batches (config 2 size, different
+    molecules each).  The union has ~4.1 k edge tiles - the size at which ``cfconv_dispatch`` takes the 8-wave build by its
+    rounds x cost rule - and ~720 node tiles (the eight-wave node chains persistent over three tiles per workgroup).  Every
+    member's rows must equal a forward of its own (2e-6: boundary sums pair differently in the union) and the C oracle's."""
+    from gcnn_keras_amd.literature import Schnet
+    from gcnn_keras_amd.ragged import RaggedTensor
+    from oracle import c_oracle
+    p = synth.schnet_params(seed=7, random_bias=True)
+    model = Schnet.make_model(depth=3)
+    model.set_weights(list(p.values()))
+    batches = [synth.qm9_like_batch(num_graphs=128, seed=1234 + k) for k in range(5)]
+    tiles = sum((int(b["edge_splits"][-1]) + 31) // 32 for b in batches)
+    assert 3072 <= tiles and 37 * ((tiles + 2047) // 2048) < 20 * ((tiles + 1023) // 1024)   # the 8-wave build's range
+    ins = [[RaggedTensor.from_numpy(b["node_number"], b["node_splits"]),
+            RaggedTensor.from_numpy(b["node_coordinates"], b["node_splits"]),
+            RaggedTensor.from_numpy(b["edge_indices"], b["edge_splits"])] for b in batches]
+    alone = [model(x).cpu().numpy() for x in ins]
+    first = [t.cpu().numpy() for t in model.fused.call_group(ins)]            # direct launch
+    assert model.fused.last == "direct"
+    again = [t.cpu().numpy() for t in model.fused.call_group(ins)]            # the group's captured graph
+    assert model.fused.last == "graph"
+    for k, b in enumerate(batches):
+        assert first[k].shape == (128, 1) and np.array_equal(first[k], again[k])
+        assert rowwise_rel(first[k], alone[k]) <= 2e-6
+        if c_oracle.available():
+            ref = c_oracle.schnet_forward(p, b["node_number"], b["node_coordinates"], b["edge_indices"], b["node_splits"],
+                                          b["edge_splits"], depth=3)
+            assert_rows_close(first[k], ref, what="default bench group, member %d vs the C oracle" % k)
+    model.fused.check_flags()
+
+
 def test_config2_graph_permutation_equivariance():
     p = synth.schnet_params(seed=7, random_bias=True)
     b = synth.qm9_like_batch(num_graphs=128, seed=1234)
