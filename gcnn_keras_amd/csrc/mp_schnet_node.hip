@@ -627,7 +627,12 @@ void launch_stage0(const NodeArgs& a, const mp_prep::EdgePrepArgs& p, int node_b
                    hipStream_t s) {
   if ((flags_arg & 66) == 66) {   // bf16-piece weight images
     // (eight-wave node workgroups; the edge-preparation workgroups of the launch are block-size agnostic: half as many)
-    const unsigned grid8 = static_cast<unsigned>(node_blocks) + (grid - static_cast<unsigned>(node_blocks) + 1) / 2;
+    // at most 64 of them: every edge workgroup first stages both row-split arrays in LDS (10 KB at 640 graphs), which is
+    // most of what a workgroup with 512 edges does - a launch group's 131 k edges on 64 workgroups (four edges per thread)
+    // instead of 256: +2 % in flight (scripts/probes/ab_stage0_edge_cap.sh); a lone 128-graph batch has 51 anyway
+    unsigned eblocks = (grid - static_cast<unsigned>(node_blocks) + 1) / 2;
+    if (eblocks > 64) eblocks = 64;
+    const unsigned grid8 = static_cast<unsigned>(node_blocks) + eblocks;
     if (flags_arg & 1) schnet_stage0_kernel<E, true, true, true, true><<<grid8, 512, 0, s>>>(a, p, node_blocks);
     else schnet_stage0_kernel<E, false, true, true, true><<<grid8, 512, 0, s>>>(a, p, node_blocks);
     return;
