@@ -496,6 +496,8 @@ def run_stream(args, d, batches=64, in_flight=4):
         edges.append(int(b["edge_splits"][-1]))
     model = Schnet.make_model(depth=DEPTH)
     model.set_weights(list(synth.schnet_params(seed=7).values()))
+    if in_flight > 1 and os.environ.get("MPENGINE_INFLIGHT_NODE_HALF", "1") != "0":
+        model.fused.cfconv_flags |= 512     # several launch sequences in flight (as engine.SchnetForward sets it)
     placed = getattr(args, "_placed_streams", None)
     streams = placed[:in_flight] if placed and len(placed) >= in_flight else [torch.cuda.Stream() for _ in range(in_flight)]
     packer = BatchPacker(items, index_item="edge_indices", node_item="node_number", slots=2 * in_flight)

@@ -16,7 +16,7 @@ int mp_schnet_forward_launch(const mp_schnet_forward_desc* d, mpStream_t stream)
              d->depth, MP_SCHNET_MAX_DEPTH);
   int rc = mp_schnet_stage0_f32(d->numbers, d->N, d->embedding, d->vocab, d->emb_dim == 128 ? 128 : 64, d->W0, d->b0,
                                 d->Wx[0], d->n, d->x, d->idx, d->M, d->node_splits, d->edge_splits, d->G, d->xyz,
-                                d->recv, d->send, d->dist, d->flags_word, d->flags & (3 | 64 | 256), stream);
+                                d->recv, d->send, d->dist, d->flags_word, d->flags & (3 | 64 | 256 | 512), stream);
   if (rc != MP_OK) return rc;
   for (int i = 0; i < d->depth; ++i) {
     rc = mp_cfconv_gauss_fused_f32(d->x, d->N, d->dist, d->bins, d->g_distance, d->g_sigma, d->g_offset, d->packed[i],
@@ -24,10 +24,10 @@ int mp_schnet_forward_launch(const mp_schnet_forward_desc* d, mpStream_t stream)
     if (rc != MP_OK) return rc;
     if (i + 1 < d->depth) {
       rc = mp_schnet_node_update_f32(d->agg, d->N, d->W2[i], d->b2[i], d->W3[i], d->b3[i], d->n, d->Wx[i + 1], d->x,
-                                     d->flags & (3 | 64), stream);
+                                     d->flags & (3 | 64 | 512), stream);
     } else {
       rc = mp_schnet_node_last_f32(d->agg, d->N, d->W2[i], d->b2[i], d->W3[i], d->b3[i], d->n, d->Wl0, d->bl0, d->Wl1,
-                                   d->bl1, d->h, d->flags & (3 | 64), stream);
+                                   d->bl1, d->h, d->flags & (3 | 64 | 512), stream);
     }
     if (rc != MP_OK) return rc;
   }

@@ -548,9 +548,13 @@ __global__ __launch_bounds__(256) void schnet_readout_kernel(const float* __rest
 // the tile prefetch (3371 vs 3328 us per forward at 225 k nodes, 397 vs 380 us at 18 k).  The persistent grid is two
 // workgroups per CU.
 template <int MODE, int E, bool FAST, bool PACKED, bool SAVE = false, bool BF = false>
-int launch_node_impl(NodeArgs a, hipStream_t s, const char* what) {
+int launch_node_impl(NodeArgs a, hipStream_t s, const char* what, int flags = 0) {
   a.ntiles = static_cast<int>((a.N + 15) / 16);
-  const int cap = BF ? 256 : 512;   // bf16-piece builds: one workgroup per CU
+  // bf16-piece builds: one workgroup per CU.  Flag bit 9 ("several launch sequences in flight"): a launch with many tiles
+  // runs on HALF the CUs - each workgroup loads its 288 KB of weight slices for twice the tiles and the other CUs serve the
+  // other sequences' kernels: +3 % for four launch groups in flight (1115 -> 1151 M edges/s), costs a lone launch
+  // latency (a single 128-graph forward 63.5 -> 70 us if it applied there: it does not, 144 tiles stay one per workgroup)
+  const int cap = BF ? (((flags & 512) && a.ntiles >= 256) ? 128 : 256) : 512;
   const int grid = a.ntiles < cap ? a.ntiles : cap;
   schnet_node_kernel<MODE, E, 1, FAST, PACKED, SAVE, BF><<<grid, BF ? 512 : 256, 0, s>>>(a);
   return mp::check_launch(what);
@@ -605,21 +609,21 @@ template <int MODE, int E>
 int launch_node(const NodeArgs& a, int flags, hipStream_t s, const char* what) {
   if constexpr (MODE == NODE_MID || MODE == NODE_LAST) {   // the energy + force pass: packed images only
     if (a.save_d2)
-      return (flags & 1) ? launch_node_impl<MODE, E, true, true, true>(a, s, what)
-                         : launch_node_impl<MODE, E, false, true, true>(a, s, what);
+      return (flags & 1) ? launch_node_impl<MODE, E, true, true, true>(a, s, what, flags)
+                         : launch_node_impl<MODE, E, false, true, true>(a, s, what, flags);
   }
   if constexpr (MODE != NODE_UPD) {   // flags bit 6 (with bit 1): mp_schnet_node_pack_bf16_f32 images, bf16-pipe GEMMs
     if ((flags & 66) == 66)
-      return (flags & 1) ? launch_node_impl<MODE, E, true, true, false, true>(a, s, what)
-                         : launch_node_impl<MODE, E, false, true, false, true>(a, s, what);
+      return (flags & 1) ? launch_node_impl<MODE, E, true, true, false, true>(a, s, what, flags)
+                         : launch_node_impl<MODE, E, false, true, false, true>(a, s, what, flags);
   }
   if constexpr (MODE != NODE_UPD) {   // flags bit 1: the weight pointers are mp_schnet_node_pack_f32 images
     if (flags & 2)
-      return (flags & 1) ? launch_node_impl<MODE, E, true, true>(a, s, what)
-                         : launch_node_impl<MODE, E, false, true>(a, s, what);
+      return (flags & 1) ? launch_node_impl<MODE, E, true, true>(a, s, what, flags)
+                         : launch_node_impl<MODE, E, false, true>(a, s, what, flags);
   }
-  return (flags & 1) ? launch_node_impl<MODE, E, true, false>(a, s, what)
-                     : launch_node_impl<MODE, E, false, false>(a, s, what);
+  return (flags & 1) ? launch_node_impl<MODE, E, true, false>(a, s, what, flags)
+                     : launch_node_impl<MODE, E, false, false>(a, s, what, flags);
 }
 
 template <int E>
@@ -699,7 +703,8 @@ int mp_schnet_stage0_f32(const float* numbers, int64_t N, const float* emb, int 
   mp_prep::EdgePrepArgs p{idx, M, node_splits, edge_splits, G, N, xyz, recv, send, dist, flags};
   // node chain: persistent over the tiles beyond one workgroup per CU (a workgroup's weight slices - 72 KB as bf16 pieces -
   // are loaded once for its tiles, not once per tile: launch groups of five batches have 720 tiles)
-  const int node_cap = ((flags_arg & 66) == 66) ? 256 : 512;   // eight-wave bf16-piece build: one workgroup per CU
+  // eight-wave bf16-piece build: one workgroup per CU; half the CUs with flag bit 9 (launch_node_impl)
+  const int node_cap = ((flags_arg & 66) == 66) ? (((flags_arg & 512) && a.ntiles >= 256) ? 128 : 256) : 512;
   const int node_blocks = a.ntiles < node_cap ? a.ntiles : node_cap;
   const int edge_blocks = static_cast<int>(mp::grid_for(M));
   hipStream_t s = mp::as_stream(stream);

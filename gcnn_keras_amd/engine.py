@@ -86,6 +86,11 @@ class SchnetForward:
         # costs a lone forward 12 us); MPENGINE_INFLIGHT_CFCONV_FLAGS overrides for experiments
         if mode == "fused" and self.in_flight > 1 and os.environ.get("MPENGINE_INFLIGHT_CFCONV_FLAGS"):
             self.model.fused.cfconv_flags = int(os.environ["MPENGINE_INFLIGHT_CFCONV_FLAGS"])
+        # launch groups in flight: the node chains of a union launch (hundreds of tiles) run on half the CUs - flag bit 9 of
+        # the node entry points, "several launch sequences in flight" - so that the other sequences' kernels find CUs and
+        # every workgroup's weight slices serve twice the tiles (+3 %); single batches (144 tiles) are not affected
+        if mode == "fused" and self.in_flight > 1 and os.environ.get("MPENGINE_INFLIGHT_NODE_HALF", "1") != "0":
+            self.model.fused.cfconv_flags |= 512
         if mode == "fused":
             self.model.fused.max_slots = max(self.model.fused.max_slots, self.in_flight)
 

@@ -256,7 +256,7 @@ class FusedSchnet:
         read back (the only host synchronisation of a batch's life, on the current stream only)."""
         self._b, self.N, self.M, self.G = b, n, m, g
         i64 = 256 if b["z"].dtype == torch.int64 else 0      # flags bit 8: int64 node numbers (the fork's input dtype)
-        self.node_flags = (self.flags_arg & (3 | 64)) | i64
+        self.node_flags = (self.flags_arg & (3 | 64 | 512)) | i64   # bit 9: node chains on half the CUs (launches in flight)
         dev = "cuda"
         if arena is not None:
             ws = work if work is not None else arena.take(_ffi.stream_handle(), n, m, g)   # (work: taken by the caller)

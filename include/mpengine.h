@@ -406,7 +406,9 @@ int mp_schnet_node_pack_f32(const float* W, int K, int U, float* packed /* K*U f
 /* The same slice order with every element as three bf16 pieces (hi + mid + lo = the FP32 value exactly): flags bit 6
  * (value 64, together with bit 1) makes the node kernels of the FORWARD run their GEMMs on the bf16 matrix pipe as an exact
  * FP32 emulation (six products per k block, FP32 accumulate: the error of the FP32 matrix instructions at 2.67x their
- * rate).  K % 32 == 0; the image holds K*U*3/2 floats. */
+ * rate).  K % 32 == 0; the image holds K*U*3/2 floats.
+ * flags bit 9 (value 512, bf16-piece build): "several launch sequences share the GPU" - a launch with 256 or more 16-node
+ * tiles runs on half the CUs (128 persistent workgroups), leaving the others to the kernels of the other sequences. */
 int mp_schnet_node_pack_bf16_f32(const float* W, int K, int U, float* packed /* K*U*3/2 floats */, mpStream_t stream);
 /* SchNetInteraction.call's node side alone (schnet_conv.py:162-164), out of place, for the layer API:
  * n_out = n_in + Dense(lin)(Dense(ssp)(agg)); agg is left untouched. */
