@@ -78,6 +78,16 @@ def test_default_bench_launch_group_rows_at_full_size():
                                           b["edge_splits"], depth=3)
             assert_rows_close(first[k], ref, what="default bench group, member %d vs the C oracle" % k)
     model.fused.check_flags()
+    # "several launch sequences in flight" (flag bit 9, what engine.SchnetForward sets for in_flight > 1): the union's node
+    # chains run on 128 persistent workgroups instead of 256 - other workgroups take the tiles, the arithmetic per tile is
+    # the same, so the rows are the same bits
+    half = Schnet.make_model(depth=3)
+    half.set_weights(list(p.values()))
+    half.fused.cfconv_flags |= 512
+    got = [t.cpu().numpy() for t in half.fused.call_group(ins)]
+    for k in range(5):
+        assert np.array_equal(got[k], first[k])
+    half.fused.check_flags()
 
 
 def test_config2_graph_permutation_equivariance():
